@@ -1,0 +1,195 @@
+// ba_device.h - per-observation arithmetic of the BA hot path, device side (f64).
+//
+// Residual:   /root/reference/src/reprojection_error.h:12-41 (rotate by angle-axis, translate,
+//             project through two general 3x4 matrices, subtract the stereo measurement).
+// Derivative: the reference takes it by autodiff (AutoDiffCostFunction<.,4,6,3>,
+//             /root/reference/src/reprojection_error.h:58), i.e. the exact derivative of the branch of
+//             ceres::AngleAxisRotatePoint that was taken.  Here it is analytic:
+//             d(Rx)/dw = -R [x]x Jr(w) with the closed-form right Jacobian on the Rodrigues branch,
+//             -[x]x on the first-order branch.
+// Loss:       HuberLoss(delta) with Ceres' corrector (rho'' <= 0 => scale r and J by sqrt(rho')).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace soslam {
+
+struct Proj {
+    double l[12];
+    double r[12];
+};
+
+// rotation matrix of the branch taken by AngleAxisRotatePoint and, if WITH_J, d(R x)/dw
+struct PoseRot {
+    double R[9];     // row-major; on the small-angle branch this is I + [w]x (not orthonormal - by design)
+    double w[3];
+    double a, b, c;  // Jr = I - b [w]x + c [w]x^2 ; a unused on the small-angle branch
+    bool small;
+};
+
+__device__ __forceinline__ void pose_rotation(const double* __restrict__ cam, PoseRot& p)
+{
+    const double wx = cam[0], wy = cam[1], wz = cam[2];
+    p.w[0] = wx; p.w[1] = wy; p.w[2] = wz;
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    if (th2 > 2.220446049250313e-16) {
+        const double th = sqrt(th2);
+        // half-angle form: 1 - cos(th) = 2 sin^2(th/2) has no cancellation at small angles
+        double sh, ch;
+        sincos(0.5 * th, &sh, &ch);
+        const double s = 2.0 * sh * ch;
+        const double oc = 2.0 * sh * sh;
+        const double c = 1.0 - oc;
+        const double ith = 1.0 / th;
+        const double kx = wx * ith, ky = wy * ith, kz = wz * ith;
+        p.R[0] = c + oc * kx * kx;      p.R[1] = -s * kz + oc * kx * ky; p.R[2] = s * ky + oc * kx * kz;
+        p.R[3] = s * kz + oc * ky * kx; p.R[4] = c + oc * ky * ky;       p.R[5] = -s * kx + oc * ky * kz;
+        p.R[6] = -s * ky + oc * kz * kx; p.R[7] = s * kx + oc * kz * ky; p.R[8] = c + oc * kz * kz;
+        // right Jacobian coefficients: Jr = I - (1-cos)/th^2 [w]x + (th - sin)/th^3 [w]x^2
+        const double ith2 = ith * ith;
+        p.b = oc * ith2;
+        // (th - sin th)/th^3: Taylor series below 0.1 rad (next term th^8/39916800 < 3e-16), direct above
+        p.c = th2 < 0.01 ? (1.0 / 6.0) - th2 * ((1.0 / 120.0) - th2 * ((1.0 / 5040.0) - th2 * (1.0 / 362880.0)))
+                         : (th - s) * ith2 * ith;
+        p.small = false;
+    } else {
+        p.R[0] = 1.0; p.R[1] = -wz; p.R[2] = wy;
+        p.R[3] = wz;  p.R[4] = 1.0; p.R[5] = -wx;
+        p.R[6] = -wy; p.R[7] = wx;  p.R[8] = 1.0;
+        p.b = 0.0; p.c = 0.0;
+        p.small = true;
+    }
+    p.a = 0.0;
+}
+
+// numerically safe (th - sin th)/th^3 and (1 - cos th)/th^2 near zero are not needed: the Rodrigues branch
+// is only taken for th^2 > eps, where the direct formulas lose at most ~eps/th^2 relative accuracy in terms
+// that are themselves O(th) corrections; see tests/test_ba_kernels_gpu.py::test_small_angles.
+
+// u, v of one camera and the 2x3 derivative wrt the camera-frame point
+__device__ __forceinline__ void project_rows(const double* __restrict__ P, const double* p, double& u, double& v,
+                                             double* __restrict__ A /* 6 */)
+{
+    const double d = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
+    const double inv = 1.0 / d;
+    u = (P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3]) * inv;
+    v = (P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7]) * inv;
+    if (A) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            A[i] = (P[i] - u * P[8 + i]) * inv;
+            A[3 + i] = (P[4 + i] - v * P[8 + i]) * inv;
+        }
+    }
+}
+
+__device__ __forceinline__ void huber(double s, double delta, double& rho0, double& rho1)
+{
+    const double b = delta * delta;
+    if (s > b) {
+        const double r = sqrt(s);
+        rho0 = 2.0 * delta * r - b;
+        rho1 = fmax(delta / r, 2.2250738585072014e-308);
+    } else {
+        rho0 = s;
+        rho1 = 1.0;
+    }
+}
+
+// residual only; returns rho(|r|^2)
+__device__ __forceinline__ double residual_cost(const PoseRot& pr, const double* __restrict__ t,
+                                                const double* x, const float4 uv, const Proj& P, double delta)
+{
+    double y[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) y[i] = pr.R[i * 3] * x[0] + pr.R[i * 3 + 1] * x[1] + pr.R[i * 3 + 2] * x[2] + t[i];
+    double ul, vl, ur, vr;
+    project_rows(P.l, y, ul, vl, nullptr);
+    project_rows(P.r, y, ur, vr, nullptr);
+    const double r0 = ul - (double)uv.x, r1 = vl - (double)uv.y, r2 = ur - (double)uv.z, r3 = vr - (double)uv.w;
+    double rho0, rho1;
+    huber(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3, delta, rho0, rho1);
+    return rho0;
+}
+
+// corrected residual r[4], J_c[24] (4x6 row-major), J_p[12] (4x3 row-major); returns rho(|r|^2)
+__device__ __forceinline__ double residual_jacobian(const PoseRot& pr, const double* __restrict__ t,
+                                                    const double* x, const float4 uv, const Proj& P, double delta,
+                                                    bool cam_fixed, double* __restrict__ r, double* __restrict__ jc,
+                                                    double* __restrict__ jp)
+{
+    double yr[3], y[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        yr[i] = pr.R[i * 3] * x[0] + pr.R[i * 3 + 1] * x[1] + pr.R[i * 3 + 2] * x[2];
+        y[i] = yr[i] + t[i];
+    }
+    double A[12], ul, vl, ur, vr;
+    project_rows(P.l, y, ul, vl, A);
+    project_rows(P.r, y, ur, vr, A + 6);
+    r[0] = ul - (double)uv.x; r[1] = vl - (double)uv.y; r[2] = ur - (double)uv.z; r[3] = vr - (double)uv.w;
+    double rho0, rho1;
+    huber(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], delta, rho0, rho1);
+    const double sw = sqrt(rho1);
+
+    // D = d(R x)/dw, 3x3
+    double D[9];
+    if (pr.small) {
+        // y = x + w x x  =>  dy/dw = -[x]x
+        D[0] = 0.0;   D[1] = x[2];  D[2] = -x[1];
+        D[3] = -x[2]; D[4] = 0.0;   D[5] = x[0];
+        D[6] = x[1];  D[7] = -x[0]; D[8] = 0.0;
+    } else {
+        // -R [x]x Jr = -[R x]x R Jr ; build M = R Jr = R - b R[w]x + c R[w]x^2, then D = -[yr]x M.
+        // R [w]x = [w]x R (w is the rotation axis direction), so M = (I - b [w]x + c [w]x^2) R... but keep
+        // the direct form: Jr first (3x3), then R*Jr.
+        const double wx = pr.w[0], wy = pr.w[1], wz = pr.w[2], b = pr.b, c = pr.c;
+        double Jr[9];
+        Jr[0] = 1.0 - c * (wy * wy + wz * wz); Jr[1] = b * wz + c * wx * wy;         Jr[2] = -b * wy + c * wx * wz;
+        Jr[3] = -b * wz + c * wx * wy;         Jr[4] = 1.0 - c * (wx * wx + wz * wz); Jr[5] = b * wx + c * wy * wz;
+        Jr[6] = b * wy + c * wx * wz;          Jr[7] = -b * wx + c * wy * wz;        Jr[8] = 1.0 - c * (wx * wx + wy * wy);
+        double M[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                M[i * 3 + j] = pr.R[i * 3] * Jr[j] + pr.R[i * 3 + 1] * Jr[3 + j] + pr.R[i * 3 + 2] * Jr[6 + j];
+        // D = -[yr]x M : row i of [yr]x M = yr x M_col... ([a]x M)_ij = a_{i+1} M_{i+2,j} - a_{i+2} M_{i+1,j}
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            D[0 * 3 + j] = -(yr[1] * M[2 * 3 + j] - yr[2] * M[1 * 3 + j]);
+            D[1 * 3 + j] = -(yr[2] * M[0 * 3 + j] - yr[0] * M[2 * 3 + j]);
+            D[2 * 3 + j] = -(yr[0] * M[1 * 3 + j] - yr[1] * M[0 * 3 + j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double a0 = A[i * 3] * sw, a1 = A[i * 3 + 1] * sw, a2 = A[i * 3 + 2] * sw;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            jc[i * 6 + j] = cam_fixed ? 0.0 : a0 * D[j] + a1 * D[3 + j] + a2 * D[6 + j];
+            jp[i * 3 + j] = a0 * pr.R[j] + a1 * pr.R[3 + j] + a2 * pr.R[6 + j];
+        }
+        jc[i * 6 + 3] = cam_fixed ? 0.0 : a0;
+        jc[i * 6 + 4] = cam_fixed ? 0.0 : a1;
+        jc[i * 6 + 5] = cam_fixed ? 0.0 : a2;
+        r[i] *= sw;
+    }
+    return rho0;
+}
+
+// inverse of a symmetric positive definite 3x3 (xx xy xz yy yz zz); ok=false when not positive definite
+__device__ __forceinline__ bool sym3_inverse(const double* __restrict__ m, double* __restrict__ inv)
+{
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    const double m2 = a * d - b * b;
+    const bool ok = (det > 0.0) && (a > 0.0) && (m2 > 0.0);
+    const double id = 1.0 / det;
+    inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+    inv[3] = (a * f - c * c) * id; inv[4] = (b * c - a * e) * id; inv[5] = m2 * id;
+    return ok;
+}
+
+}  // namespace soslam

@@ -1,0 +1,94 @@
+// ba_kernels.h - launch wrappers of the BA device kernels (definitions in ba_kernels.hip).
+// All pointers are device pointers; every launch is asynchronous on `s`.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ba_device.h"
+
+namespace soslam {
+
+constexpr int kTileObs = 256;        // observations per linearize/cost workgroup (one camera per tile)
+constexpr int kTileVals = 28;        // 21 (J_c^T J_c upper) + 6 (J_c^T r) + 1 (rho)
+constexpr int kJcRow = 24;           // f64 per observation in the J_c array (4x6 row-major, 192 B)
+constexpr int kJprRow = 16;          // f64 per observation in the [J_p | r] array (4x3 row-major + 4, 128 B)
+constexpr int kBatchObs = 128;       // observations staged per Schur batch
+constexpr int kBatchPts = 128;       // points per Schur batch (upper bound)
+constexpr int kPointBlock = 256;     // threads per block of the per-point kernels
+
+// scalar slots (device f64)
+enum {
+    SC_COST_X = 0,                                    // this rank's cost at the linearisation point
+    SC_CAND_COST = 1, SC_MCC_PTS = 2, SC_STEP2_PTS = 3, SC_X2_PTS = 4, SC_GDOT_PTS = 5,  // summed over ranks
+    SC_GMAX_PTS = 6, SC_SCHUR_STATUS = 7,
+    SC_MCC_CAM = 8, SC_STEP2_CAM = 9, SC_X2_CAM = 10, SC_GDOT_CAM = 11, SC_GMAX_CAM = 12,  // replicated
+    SC_LIN_ITERS = 13, SC_LIN_RESID = 14, SC_LIN_STATUS = 15,
+    SC_COUNT = 16
+};
+
+struct Tile {      // one workgroup of ba_linearize / ba_cost
+    uint32_t cam;
+    uint32_t start;  // first observation (camera-major index)
+    uint32_t count;  // <= kTileObs
+    uint32_t pad;
+};
+
+struct SchurChunk {  // one workgroup of ba_schur
+    uint32_t batch_begin, batch_end;
+    uint32_t n_local;    // local cameras used (<= KMAX)
+    uint32_t pad;
+};
+
+struct SchurBatch {
+    uint32_t q_begin, q_end;  // point-major observation positions
+    uint32_t p_begin, p_end;  // internal point range
+};
+
+struct LmDiag {     // what a kernel needs to rebuild the point damping
+    double radius, lo, hi;
+};
+
+void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
+                      const double* cams, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
+                      double* jc, double* jpr, double* tile_part);
+
+void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
+                 const double* cams, const double* pts, const Proj& P, double delta, double* cost_part);
+
+// out[0] = scale * sum_{i<n} in[i*stride + offset], one workgroup, fixed order (bitwise reproducible)
+void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out);
+// per-workgroup partials [n][5] = {sum, sum, sum, sum, max} -> out[0..4]
+void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
+
+void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
+                       const double* tile_part, double* B /* [F][36] */, double* gc /* [F][6] */);
+
+void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs,
+                         const double* jpr, double* C /* [n_pt][6] */, double* gp /* [n_pt][3] */);
+
+void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacobi, double* sp);
+
+void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
+                  const int32_t* chunk_blocks, const int32_t* chunk_cams, const uint32_t* pt_obs,
+                  const uint32_t* q_pt, const uint8_t* q_slot, const double* jc, const double* jpr,
+                  const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv,
+                  double* S, double* rhs, double* scal);
+
+void launch_schur_finalize(hipStream_t s, uint32_t n_free, const double* B, const double* gc,
+                           const int32_t* diag_block, double* S, double* rhs, double* diagB, double* gc_red);
+
+void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,
+                     LmDiag lm, const int32_t* diag_block, double* S, double* lc);
+
+void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams,
+                       const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid,
+                       double* cams_out, double* dc_full, double* scal);
+
+void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs,
+                    const uint32_t* obs_cam, const double* jc, const double* jpr, const double* dc_full,
+                    const double* Cinv, const double* C, const double* gp, const double* sp, const double* pts,
+                    LmDiag lm, double bound_lo, double bound_hi, double* pts_out, double* dp, double* part);
+
+}  // namespace soslam

@@ -1,0 +1,630 @@
+// ba_kernels.hip - HIP kernels of the bundle-adjustment hot path for gfx950 (CDNA4, wave64).
+//
+// Data layout in HBM:
+//   uv      [n_obs] float4          camera-major observation order (bucketed by camera)
+//   obs_pt  [n_obs] u32             internal point id (points sorted by first camera)
+//   jc      [n_obs][24] f64         loss-corrected 4x6 pose Jacobian, 192-B rows
+//   jpr     [n_obs][16] f64         loss-corrected 4x3 point Jacobian + 4 residuals, 128-B rows
+//   C/gp    [n_pt][6] / [n_pt][3]   per-point J_p^T J_p (xx xy xz yy yz zz) and J_p^T r
+//   S       [n_blocks][36]          upper block-sparse reduced camera matrix (6x6 row-major blocks)
+// Every kernel is HBM-bound streaming / gather work at ~2 flop/B; nothing here is GEMM-shaped.
+#include "ba_kernels.h"
+
+namespace soslam {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
+    return x;
+}
+
+__device__ __forceinline__ double wave_max(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_down(x, off, kWave));
+    return x;
+}
+
+__device__ __forceinline__ double point_lambda(double cdiag, double s, const LmDiag& lm)
+{
+    const double s2 = s * s;
+    return fmin(fmax(s2 * cdiag, lm.lo), lm.hi) / (lm.radius * s2);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1  ba_linearize: one workgroup per camera tile (<= 256 observations of ONE camera, so the pose is
+// workgroup-uniform and arrives through scalar loads).  Each lane evaluates one observation, writes its
+// corrected Jacobian rows, and the workgroup reduces J_c^T J_c / J_c^T r / rho with wave shuffles + LDS.
+// Algorithmic bytes per observation: 16 (uv) + 4 (point id) + 24 (point) in, 192 + 128 out = 364
+// (SURVEY.md section 8(d) counts 368 with the second index).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTileObs) void ba_linearize_kernel(
+    const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
+    const double* __restrict__ cams, const double* __restrict__ pts, const int32_t* __restrict__ cam_free,
+    const Proj P, const double delta, double* __restrict__ jc_out, double* __restrict__ jpr_out,
+    double* __restrict__ tile_part)
+{
+    __shared__ double red[(kTileObs / kWave) * kTileVals];
+    const Tile t = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const bool fixed = cam_free[t.cam] < 0;
+    const double* cam = cams + 6 * (size_t)t.cam;
+    PoseRot pr;
+    pose_rotation(cam, pr);
+    const double tr[3] = {cam[3], cam[4], cam[5]};
+
+    double v[kTileVals];
+#pragma unroll
+    for (int i = 0; i < kTileVals; i++) v[i] = 0.0;
+
+    if (tid < (int)t.count) {
+        const size_t k = (size_t)t.start + tid;
+        const float4 m = uv[k];
+        const uint32_t p = obs_pt[k];
+        const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+        double r[4], jc[24], jp[12];
+        v[27] = residual_jacobian(pr, tr, x, m, P, delta, fixed, r, jc, jp);
+
+        double2* jrow = reinterpret_cast<double2*>(jc_out + kJcRow * k);
+#pragma unroll
+        for (int i = 0; i < 12; i++) jrow[i] = make_double2(jc[2 * i], jc[2 * i + 1]);
+        double2* prow = reinterpret_cast<double2*>(jpr_out + kJprRow * k);
+#pragma unroll
+        for (int i = 0; i < 6; i++) prow[i] = make_double2(jp[2 * i], jp[2 * i + 1]);
+        prow[6] = make_double2(r[0], r[1]);
+        prow[7] = make_double2(r[2], r[3]);
+
+        if (!fixed) {
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = a; b < 6; b++)
+                    v[idx++] = jc[a] * jc[b] + jc[6 + a] * jc[6 + b] + jc[12 + a] * jc[12 + b] + jc[18 + a] * jc[18 + b];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+                v[21 + a] = jc[a] * r[0] + jc[6 + a] * r[1] + jc[12 + a] * r[2] + jc[18 + a] * r[3];
+        }
+    }
+    const int wave = tid / kWave, lane = tid % kWave;
+#pragma unroll
+    for (int i = 0; i < kTileVals; i++) {
+        const double sum = wave_sum(v[i]);
+        if (lane == 0) red[wave * kTileVals + i] = sum;
+    }
+    __syncthreads();
+    if (tid < kTileVals) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < kTileObs / kWave; w++) sum += red[w * kTileVals + tid];
+        tile_part[(size_t)blockIdx.x * kTileVals + tid] = sum;
+    }
+}
+
+// K2  ba_cost: residual + loss only, same tiling.  48 B per observation in, 8 B per tile out.
+__global__ __launch_bounds__(kTileObs) void ba_cost_kernel(
+    const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
+    const double* __restrict__ cams, const double* __restrict__ pts, const Proj P, const double delta,
+    double* __restrict__ cost_part)
+{
+    __shared__ double red[kTileObs / kWave];
+    const Tile t = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    const double* cam = cams + 6 * (size_t)t.cam;
+    PoseRot pr;
+    pose_rotation(cam, pr);
+    const double tr[3] = {cam[3], cam[4], cam[5]};
+    double rho = 0.0;
+    if (tid < (int)t.count) {
+        const size_t k = (size_t)t.start + tid;
+        const uint32_t p = obs_pt[k];
+        const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+        rho = residual_cost(pr, tr, x, uv[k], P, delta);
+    }
+    const double sum = wave_sum(rho);
+    if (tid % kWave == 0) red[tid / kWave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kTileObs / kWave; w++) s += red[w];
+        cost_part[blockIdx.x] = s;
+    }
+}
+
+// fixed-order sum of a strided column: one workgroup, each lane a fixed subsequence, then a fixed tree
+__global__ __launch_bounds__(1024) void sum_strided_kernel(const double* __restrict__ in, uint32_t n, uint32_t stride,
+                                                            uint32_t offset, double scale, double* __restrict__ out)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) s += in[(size_t)i * stride + offset];
+    s = wave_sum(s);
+    if (threadIdx.x % kWave == 0) red[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; w++) t += red[w];
+        out[0] = scale * t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void sum5_kernel(const double* __restrict__ in, uint32_t n, double* __restrict__ out)
+{
+    __shared__ double red[16 * 5];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, mx = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const double* v = in + 5 * (size_t)i;
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        mx = fmax(mx, v[4]);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); mx = wave_max(mx);
+    if (threadIdx.x % kWave == 0) {
+        double* o = red + (threadIdx.x / kWave) * 5;
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0, e = 0.0;
+        for (int w = 0; w < 16; w++) { a += red[w * 5]; b += red[w * 5 + 1]; c += red[w * 5 + 2]; d += red[w * 5 + 3]; e = fmax(e, red[w * 5 + 4]); }
+        out[0] = a; out[1] = b; out[2] = c; out[3] = d; out[4] = e;
+    }
+}
+
+// K3  camera blocks from the tile partials: one 64-lane workgroup per camera, lanes 0..26 each own one
+// value and add the camera's tiles in order (bitwise reproducible).
+__global__ __launch_bounds__(64) void ba_cam_reduce_kernel(const uint32_t* __restrict__ cam_tile_start,
+                                                           const int32_t* __restrict__ cam_free,
+                                                           const double* __restrict__ tile_part,
+                                                           double* __restrict__ B, double* __restrict__ gc)
+{
+    const uint32_t cam = blockIdx.x;
+    const int32_t f = cam_free[cam];
+    const int v = threadIdx.x;
+    if (f < 0 || v >= 27) return;
+    double s = 0.0;
+    for (uint32_t t = cam_tile_start[cam]; t < cam_tile_start[cam + 1]; t++) s += tile_part[(size_t)t * kTileVals + v];
+    if (v < 21) {
+        int a = 0, rem = v;
+        while (rem >= 6 - a) { rem -= 6 - a; a++; }
+        const int b = a + rem;
+        B[36 * (size_t)f + a * 6 + b] = s;
+        B[36 * (size_t)f + b * 6 + a] = s;
+    } else {
+        gc[6 * (size_t)f + (v - 21)] = s;
+    }
+}
+
+// K4  per-point J_p^T J_p and J_p^T r through the point-major index; one lane per point, each
+// observation a 128-B row.
+__global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n_pt, const uint32_t* __restrict__ pt_start,
+                                                                      const uint32_t* __restrict__ pt_obs,
+                                                                      const double* __restrict__ jpr,
+                                                                      double* __restrict__ C, double* __restrict__ gp)
+{
+    const uint32_t p = blockIdx.x * kPointBlock + threadIdx.x;
+    if (p >= n_pt) return;
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2 = 0;
+    for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
+        const double2* row = reinterpret_cast<const double2*>(jpr + kJprRow * (size_t)pt_obs[q]);
+        double w[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const double2 d = row[i]; w[2 * i] = d.x; w[2 * i + 1] = d.y; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double a = w[i * 3], b = w[i * 3 + 1], c = w[i * 3 + 2], r = w[12 + i];
+            c0 += a * a; c1 += a * b; c2 += a * c; c3 += b * b; c4 += b * c; c5 += c * c;
+            g0 += a * r; g1 += b * r; g2 += c * r;
+        }
+    }
+    double* Cp = C + 6 * (size_t)p;
+    Cp[0] = c0; Cp[1] = c1; Cp[2] = c2; Cp[3] = c3; Cp[4] = c4; Cp[5] = c5;
+    double* g = gp + 3 * (size_t)p;
+    g[0] = g0; g[1] = g1; g[2] = g2;
+}
+
+__global__ __launch_bounds__(kPointBlock) void ba_point_scale_kernel(uint32_t n_pt, const double* __restrict__ C, int jacobi,
+                                                                     double* __restrict__ sp)
+{
+    const uint32_t p = blockIdx.x * kPointBlock + threadIdx.x;
+    if (p >= n_pt) return;
+    const double* Cp = C + 6 * (size_t)p;
+    sp[3 * (size_t)p] = jacobi ? 1.0 / (1.0 + sqrt(Cp[0])) : 1.0;
+    sp[3 * (size_t)p + 1] = jacobi ? 1.0 / (1.0 + sqrt(Cp[3])) : 1.0;
+    sp[3 * (size_t)p + 2] = jacobi ? 1.0 / (1.0 + sqrt(Cp[5])) : 1.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5  ba_schur: one workgroup per chunk of consecutive points whose cameras fit a window of KMAX local
+// slots.  Per batch (<= 128 observations) the first lanes form W = J_c^T J_p, invert the damped point
+// block in registers and stage W, Y = W Cinv in LDS; then every lane owns a fixed half (3x6) of one
+// local camera-pair block and accumulates Y_a W_b^T over the batch's points in REGISTERS (no atomics,
+// fixed order).  One flush per chunk adds the window into the global block-sparse S with f64 atomics.
+// ---------------------------------------------------------------------------------------------------
+template <int KMAX, int NT>
+__global__ __launch_bounds__(NT) void ba_schur_kernel(
+    const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches,
+    const int32_t* __restrict__ chunk_blocks, const int32_t* __restrict__ chunk_cams,
+    const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_pt, const uint8_t* __restrict__ q_slot,
+    const double* __restrict__ jc, const double* __restrict__ jpr, const double* __restrict__ C,
+    const double* __restrict__ gp, const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv,
+    double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ scal)
+{
+    constexpr int NPAIR = KMAX * (KMAX + 1) / 2;
+    constexpr int NITEM = 2 * NPAIR + KMAX;
+    constexpr int IPT = (NITEM + NT - 1) / NT;
+    static_assert(NT >= kBatchObs, "staging needs one lane per batch observation");
+    __shared__ double Wl[kBatchObs * 18];
+    __shared__ double Yl[kBatchObs * 18];
+    __shared__ double gl[kBatchObs * 3];
+    __shared__ uint8_t tab[kBatchPts * KMAX];
+
+    const SchurChunk ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x;
+
+    // item decode: kind 0/1 = rows 0-2 / 3-5 of pair (a,b); 2 = rhs of local camera a; 3 = idle
+    int ia[IPT], ib[IPT], kind[IPT], pair_id[IPT];
+    double acc[IPT][18];
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const int it = tid + j * NT;
+        ia[j] = 0; ib[j] = 0; kind[j] = 3; pair_id[j] = 0;
+        if (it < 2 * NPAIR) {
+            int pair = it >> 1, a = 0;
+            pair_id[j] = pair;
+            while (pair >= KMAX - a) { pair -= KMAX - a; a++; }
+            ia[j] = a; ib[j] = a + pair;
+            kind[j] = ((uint32_t)ib[j] < ch.n_local) ? (it & 1) : 3;
+        } else if (it < NITEM) {
+            ia[j] = it - 2 * NPAIR;
+            kind[j] = ((uint32_t)ia[j] < ch.n_local) ? 2 : 3;
+        }
+#pragma unroll
+        for (int i = 0; i < 18; i++) acc[j][i] = 0.0;
+    }
+
+    for (uint32_t bi = ch.batch_begin; bi < ch.batch_end; bi++) {
+        const SchurBatch bt = batches[bi];
+        const int nq = (int)(bt.q_end - bt.q_begin), np = (int)(bt.p_end - bt.p_begin);
+        __syncthreads();
+        for (int i = tid; i < np * KMAX; i += NT) tab[i] = 255;
+        __syncthreads();
+        if (tid < nq) {
+            const uint32_t q = bt.q_begin + tid;
+            const size_t k = pt_obs[q];
+            const uint32_t p = q_pt[q];
+            const uint8_t slot = q_slot[q];
+            const double2* jcr = reinterpret_cast<const double2*>(jc + kJcRow * k);
+            const double2* jr = reinterpret_cast<const double2*>(jpr + kJprRow * k);
+            double a[24], b[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const double2 d = jcr[i]; a[2 * i] = d.x; a[2 * i + 1] = d.y; }
+#pragma unroll
+            for (int i = 0; i < 6; i++) { const double2 d = jr[i]; b[2 * i] = d.x; b[2 * i + 1] = d.y; }
+            const double* Cp = C + 6 * (size_t)p;
+            const double* s3 = sp + 3 * (size_t)p;
+            double m[6] = {Cp[0], Cp[1], Cp[2], Cp[3], Cp[4], Cp[5]}, ci[6];
+            m[0] += point_lambda(Cp[0], s3[0], lm);
+            m[3] += point_lambda(Cp[3], s3[1], lm);
+            m[5] += point_lambda(Cp[5], s3[2], lm);
+            if (!sym3_inverse(m, ci)) scal[SC_SCHUR_STATUS] = 1.0;
+            double* Wt = Wl + tid * 18;
+            double* Yt = Yl + tid * 18;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double w0 = a[r] * b[0] + a[6 + r] * b[3] + a[12 + r] * b[6] + a[18 + r] * b[9];
+                const double w1 = a[r] * b[1] + a[6 + r] * b[4] + a[12 + r] * b[7] + a[18 + r] * b[10];
+                const double w2 = a[r] * b[2] + a[6 + r] * b[5] + a[12 + r] * b[8] + a[18 + r] * b[11];
+                Wt[r * 3] = w0; Wt[r * 3 + 1] = w1; Wt[r * 3 + 2] = w2;
+                Yt[r * 3] = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
+                Yt[r * 3 + 1] = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
+                Yt[r * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
+            }
+            gl[tid * 3] = gp[3 * (size_t)p]; gl[tid * 3 + 1] = gp[3 * (size_t)p + 1]; gl[tid * 3 + 2] = gp[3 * (size_t)p + 2];
+            if (slot != 255) tab[(p - bt.p_begin) * KMAX + slot] = (uint8_t)tid;
+            if (tid == 0 || q_pt[q - 1] != p) {
+                double* o = Cinv + 6 * (size_t)p;
+#pragma unroll
+                for (int i = 0; i < 6; i++) o[i] = ci[i];
+            }
+        }
+        __syncthreads();
+        for (int pl = 0; pl < np; pl++) {
+            const uint8_t* trow = tab + pl * KMAX;
+#pragma unroll
+            for (int j = 0; j < IPT; j++) {
+                if (kind[j] < 2) {
+                    const int ta = trow[ia[j]], tb = trow[ib[j]];
+                    if (ta != 255 && tb != 255) {
+                        const double* Y = Yl + ta * 18 + kind[j] * 9;
+                        const double* W = Wl + tb * 18;
+#pragma unroll
+                        for (int r = 0; r < 3; r++)
+#pragma unroll
+                            for (int c = 0; c < 6; c++)
+                                acc[j][r * 6 + c] += Y[r * 3] * W[c * 3] + Y[r * 3 + 1] * W[c * 3 + 1] + Y[r * 3 + 2] * W[c * 3 + 2];
+                    }
+                } else if (kind[j] == 2) {
+                    const int ta = trow[ia[j]];
+                    if (ta != 255) {
+                        const double* Y = Yl + ta * 18;
+                        const double* g = gl + ta * 3;
+#pragma unroll
+                        for (int r = 0; r < 6; r++) acc[j][r] += Y[r * 3] * g[0] + Y[r * 3 + 1] * g[1] + Y[r * 3 + 2] * g[2];
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        if (kind[j] < 2) {
+            const int32_t blk = chunk_blocks[(size_t)blockIdx.x * NPAIR + pair_id[j]];
+            if (blk >= 0) {
+                double* o = S + 36 * (size_t)blk + kind[j] * 18;
+#pragma unroll
+                for (int i = 0; i < 18; i++) unsafeAtomicAdd(o + i, -acc[j][i]);
+            }
+        } else if (kind[j] == 2) {
+            const int32_t f = chunk_cams[(size_t)blockIdx.x * KMAX + ia[j]];
+            if (f >= 0) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) unsafeAtomicAdd(rhs + 6 * (size_t)f + r, acc[j][r]);
+            }
+        }
+    }
+}
+
+// S_ff += B_f, rhs_f -= g_c,f (this rank's share), and export diag(B), g_c for the all-reduce
+__global__ __launch_bounds__(64) void ba_schur_finalize_kernel(uint32_t n_free, const double* __restrict__ B,
+                                                               const double* __restrict__ gc,
+                                                               const int32_t* __restrict__ diag_block,
+                                                               double* __restrict__ S, double* __restrict__ rhs,
+                                                               double* __restrict__ diagB, double* __restrict__ gc_red)
+{
+    const uint32_t f = blockIdx.x;
+    const int t = threadIdx.x;
+    if (f >= n_free) return;
+    if (t < 36) S[36 * (size_t)diag_block[f] + t] += B[36 * (size_t)f + t];
+    if (t < 6) {
+        rhs[6 * (size_t)f + t] -= gc[6 * (size_t)f + t];
+        diagB[6 * (size_t)f + t] = B[36 * (size_t)f + t * 7];
+        gc_red[6 * (size_t)f + t] = gc[6 * (size_t)f + t];
+    }
+}
+
+// after the all-reduce: Jacobi scale (first linearisation only), camera damping onto the diagonal of S
+__global__ __launch_bounds__(256) void ba_cam_damp_kernel(uint32_t n_free, const double* __restrict__ diagB,
+                                                          double* __restrict__ sc, int init_scale, int jacobi,
+                                                          const LmDiag lm, const int32_t* __restrict__ diag_block,
+                                                          double* __restrict__ S, double* __restrict__ lc)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_free * 6) return;
+    const uint32_t f = i / 6, a = i % 6;
+    const double d = diagB[i];
+    double s = sc[i];
+    if (init_scale) {
+        s = jacobi ? 1.0 / (1.0 + sqrt(d)) : 1.0;
+        sc[i] = s;
+    }
+    const double lam = point_lambda(d, s, lm);
+    lc[i] = lam;
+    S[36 * (size_t)diag_block[f] + a * 7] += lam;
+}
+
+// candidate cameras, full-length camera step, camera share of the step scalars (one workgroup)
+__global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, const int32_t* __restrict__ cam_free,
+                                                            const double* __restrict__ cams,
+                                                            const double* __restrict__ dc_free,
+                                                            const double* __restrict__ lc, const double* __restrict__ gc_red,
+                                                            const double* __restrict__ lin_resid,
+                                                            double* __restrict__ cams_out, double* __restrict__ dc_full,
+                                                            double* __restrict__ scal)
+{
+    __shared__ double red[4 * 5];
+    double mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_cam * 6; i += 256) {
+        const uint32_t c = i / 6, a = i % 6;
+        const int32_t f = cam_free[c];
+        const double x = cams[i];
+        double d = 0.0;
+        if (f >= 0) {
+            const uint32_t fi = 6 * (uint32_t)f + a;
+            d = dc_free[fi];
+            const double g = gc_red[fi];
+            mcc += 0.5 * (lc[fi] * d * d - g * d);
+            if (lin_resid) mcc += 0.5 * d * lin_resid[fi];
+            gd += g * d;
+            x2 += x * x;
+            gm = fmax(gm, fabs(g));
+        }
+        const double xn = x + d;
+        const double e = xn - x;
+        st2 += e * e;
+        cams_out[i] = xn;
+        dc_full[i] = d;
+    }
+    mcc = wave_sum(mcc); st2 = wave_sum(st2); x2 = wave_sum(x2); gd = wave_sum(gd); gm = wave_max(gm);
+    if (threadIdx.x % kWave == 0) {
+        double* o = red + (threadIdx.x / kWave) * 5;
+        o[0] = mcc; o[1] = st2; o[2] = x2; o[3] = gd; o[4] = gm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0, c = 0, d = 0, e = 0;
+        for (int w = 0; w < 4; w++) { a += red[w * 5]; b += red[w * 5 + 1]; c += red[w * 5 + 2]; d += red[w * 5 + 3]; e = fmax(e, red[w * 5 + 4]); }
+        scal[SC_MCC_CAM] = a; scal[SC_STEP2_CAM] = b; scal[SC_X2_CAM] = c; scal[SC_GDOT_CAM] = d; scal[SC_GMAX_CAM] = e;
+    }
+}
+
+// K8  back-substitution dp = -Cinv (g_p + sum_obs J_p^T (J_c dc)), candidate point with the box bounds,
+// per-workgroup partials {model-cost share, |step|^2, |x|^2, g.step, max|g|}
+__global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
+    uint32_t n_pt, const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_obs,
+    const uint32_t* __restrict__ obs_cam, const double* __restrict__ jc, const double* __restrict__ jpr,
+    const double* __restrict__ dc_full, const double* __restrict__ Cinv, const double* __restrict__ C,
+    const double* __restrict__ gp, const double* __restrict__ sp, const double* __restrict__ pts, const LmDiag lm,
+    const double bound_lo, const double bound_hi, double* __restrict__ pts_out, double* __restrict__ dp_out,
+    double* __restrict__ part)
+{
+    __shared__ double red[(kPointBlock / kWave) * 5];
+    const uint32_t p = blockIdx.x * kPointBlock + threadIdx.x;
+    double mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
+    if (p < n_pt) {
+        const double g[3] = {gp[3 * (size_t)p], gp[3 * (size_t)p + 1], gp[3 * (size_t)p + 2]};
+        double t0 = g[0], t1 = g[1], t2 = g[2];
+        for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
+            const size_t k = pt_obs[q];
+            const double* d = dc_full + 6 * (size_t)obs_cam[k];
+            const double d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
+            const double2* jcr = reinterpret_cast<const double2*>(jc + kJcRow * k);
+            const double2* jr = reinterpret_cast<const double2*>(jpr + kJprRow * k);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double2 a0 = jcr[i * 3], a1 = jcr[i * 3 + 1], a2 = jcr[i * 3 + 2];
+                const double m = a0.x * d0 + a0.y * d1 + a1.x * d2 + a1.y * d3 + a2.x * d4 + a2.y * d5;
+                const double* jp = reinterpret_cast<const double*>(jr) + i * 3;
+                t0 += jp[0] * m; t1 += jp[1] * m; t2 += jp[2] * m;
+            }
+        }
+        const double* ci = Cinv + 6 * (size_t)p;
+        const double e[3] = {-(ci[0] * t0 + ci[1] * t1 + ci[2] * t2), -(ci[1] * t0 + ci[3] * t1 + ci[4] * t2),
+                             -(ci[2] * t0 + ci[4] * t1 + ci[5] * t2)};
+        const double* Cp = C + 6 * (size_t)p;
+        const double cd[3] = {Cp[0], Cp[3], Cp[5]};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double x = pts[3 * (size_t)p + a];
+            const double xn = fmin(fmax(x + e[a], bound_lo), bound_hi);
+            const double st = xn - x;
+            pts_out[3 * (size_t)p + a] = xn;
+            dp_out[3 * (size_t)p + a] = e[a];
+            mcc += 0.5 * (point_lambda(cd[a], sp[3 * (size_t)p + a], lm) * e[a] * e[a] - g[a] * e[a]);
+            st2 += st * st;
+            x2 += x * x;
+            gd += g[a] * e[a];
+            gm = fmax(gm, fabs(g[a]));
+        }
+    }
+    mcc = wave_sum(mcc); st2 = wave_sum(st2); x2 = wave_sum(x2); gd = wave_sum(gd); gm = wave_max(gm);
+    if (threadIdx.x % kWave == 0) {
+        double* o = red + (threadIdx.x / kWave) * 5;
+        o[0] = mcc; o[1] = st2; o[2] = x2; o[3] = gd; o[4] = gm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0, c = 0, d = 0, e = 0;
+        for (int w = 0; w < kPointBlock / kWave; w++) { a += red[w * 5]; b += red[w * 5 + 1]; c += red[w * 5 + 2]; d += red[w * 5 + 3]; e = fmax(e, red[w * 5 + 4]); }
+        double* o = part + 5 * (size_t)blockIdx.x;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = d; o[4] = e;
+    }
+}
+
+}  // namespace
+
+// ---- launch wrappers --------------------------------------------------------------------------------
+
+void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
+                      const double* cams, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
+                      double* jc, double* jpr, double* tile_part)
+{
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(ba_linearize_kernel, dim3(n_tiles), dim3(kTileObs), 0, s, tiles, uv, obs_pt, cams, pts, cam_free, P,
+                       delta, jc, jpr, tile_part);
+}
+
+void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
+                 const double* cams, const double* pts, const Proj& P, double delta, double* cost_part)
+{
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(ba_cost_kernel, dim3(n_tiles), dim3(kTileObs), 0, s, tiles, uv, obs_pt, cams, pts, P, delta, cost_part);
+}
+
+void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out)
+{
+    hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, in, n, stride, offset, scale, out);
+}
+
+void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out)
+{
+    hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(1024), 0, s, in, n, out);
+}
+
+void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
+                       const double* tile_part, double* B, double* gc)
+{
+    if (!n_cam) return;
+    hipLaunchKernelGGL(ba_cam_reduce_kernel, dim3(n_cam), dim3(64), 0, s, cam_tile_start, cam_free, tile_part, B, gc);
+}
+
+void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs,
+                         const double* jpr, double* C, double* gp)
+{
+    if (!n_pt) return;
+    hipLaunchKernelGGL(ba_point_reduce_kernel, dim3((n_pt + kPointBlock - 1) / kPointBlock), dim3(kPointBlock), 0, s, n_pt,
+                       pt_start, pt_obs, jpr, C, gp);
+}
+
+void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacobi, double* sp)
+{
+    if (!n_pt) return;
+    hipLaunchKernelGGL(ba_point_scale_kernel, dim3((n_pt + kPointBlock - 1) / kPointBlock), dim3(kPointBlock), 0, s, n_pt, C,
+                       jacobi, sp);
+}
+
+void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
+                  const int32_t* chunk_blocks, const int32_t* chunk_cams, const uint32_t* pt_obs,
+                  const uint32_t* q_pt, const uint8_t* q_slot, const double* jc, const double* jpr,
+                  const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv,
+                  double* S, double* rhs, double* scal)
+{
+    if (!n_chunks) return;
+    if (kmax <= 16)
+        hipLaunchKernelGGL((ba_schur_kernel<16, 320>), dim3(n_chunks), dim3(320), 0, s, chunks, batches, chunk_blocks,
+                           chunk_cams, pt_obs, q_pt, q_slot, jc, jpr, C, gp, sp, lm, Cinv, S, rhs, scal);
+    else
+        hipLaunchKernelGGL((ba_schur_kernel<32, 576>), dim3(n_chunks), dim3(576), 0, s, chunks, batches, chunk_blocks,
+                           chunk_cams, pt_obs, q_pt, q_slot, jc, jpr, C, gp, sp, lm, Cinv, S, rhs, scal);
+}
+
+void launch_schur_finalize(hipStream_t s, uint32_t n_free, const double* B, const double* gc,
+                           const int32_t* diag_block, double* S, double* rhs, double* diagB, double* gc_red)
+{
+    if (!n_free) return;
+    hipLaunchKernelGGL(ba_schur_finalize_kernel, dim3(n_free), dim3(64), 0, s, n_free, B, gc, diag_block, S, rhs, diagB, gc_red);
+}
+
+void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,
+                     LmDiag lm, const int32_t* diag_block, double* S, double* lc)
+{
+    if (!n_free) return;
+    hipLaunchKernelGGL(ba_cam_damp_kernel, dim3((n_free * 6 + 255) / 256), dim3(256), 0, s, n_free, diagB, sc, init_scale, jacobi,
+                       lm, diag_block, S, lc);
+}
+
+void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams,
+                       const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid,
+                       double* cams_out, double* dc_full, double* scal)
+{
+    hipLaunchKernelGGL(ba_cam_update_kernel, dim3(1), dim3(256), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red, lin_resid,
+                       cams_out, dc_full, scal);
+}
+
+void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs,
+                    const uint32_t* obs_cam, const double* jc, const double* jpr, const double* dc_full,
+                    const double* Cinv, const double* C, const double* gp, const double* sp, const double* pts,
+                    LmDiag lm, double bound_lo, double bound_hi, double* pts_out, double* dp, double* part)
+{
+    if (!n_pt) return;
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3((n_pt + kPointBlock - 1) / kPointBlock), dim3(kPointBlock), 0, s, n_pt, pt_start,
+                       pt_obs, obs_cam, jc, jpr, dc_full, Cinv, C, gp, sp, pts, lm, bound_lo, bound_hi, pts_out, dp, part);
+}
+
+}  // namespace soslam

@@ -1,0 +1,1111 @@
+// ba_solver.hip - host side of libsoslam_ba: index construction, device state, the Levenberg-Marquardt
+// controller and the C ABI of include/soslam_ba.h.
+//
+// The controller restates Ceres' TrustRegionMinimizer + LevenbergMarquardtStrategy for the problem
+// BundleAdjuster::Optimize builds (/root/reference/src/bundle_adjuster.cpp:39-118):
+// all arithmetic on problem-sized data runs in the HIP kernels of ba_kernels.hip / linsolve.hip; the host
+// reads back one small block of scalars per iteration and takes the accept/reject decision.
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <iterator>
+#include <memory>
+#include <numeric>
+
+#include "../host/mat4f.h"
+#include "ba_kernels.h"
+#include "common.h"
+#include "linsolve.h"
+
+namespace soslam {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+namespace {
+
+double now_sec()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+constexpr int kDenseAutoLimit = 1200;   // camera dof up to which AUTO picks the dense Cholesky
+
+}  // namespace
+
+}  // namespace soslam
+
+using namespace soslam;
+
+struct soslam_ba {
+    soslam_ba_options opt{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int device = 0;
+    Proj proj{};
+    bool have_proj = false, have_problem = false, have_state = false;
+
+    // dimensions
+    uint32_t n_cam = 0, n_pt = 0, n_obs = 0, n_free = 0, n_tiles = 0, n_chunks = 0, n_batches = 0, n_blocks = 0;
+    uint32_t n_point_blocks = 0;
+    int kmax = 16;
+    int solver = SOSLAM_SOLVER_PCG;
+    double setup_seconds = 0.0;
+
+    // host-side permutations (internal <-> caller order)
+    std::vector<uint32_t> pt_int2user, pt_user2int, obs_int2user;
+    std::vector<int32_t> h_cam_free;
+    std::vector<uint32_t> h_blk_row, h_blk_col;
+    std::vector<std::pair<uint32_t, uint32_t>> covis;   // job-wide camera pairs (multi-GPU)
+
+    // static device data
+    DevBuf<float4> uv;
+    DevBuf<uint32_t> obs_pt, obs_cam, cam_tile_start, pt_start, pt_obs, q_pt;
+    DevBuf<uint8_t> q_slot, ent_trans;
+    DevBuf<Tile> tiles;
+    DevBuf<int32_t> cam_free, chunk_blocks, chunk_cams, diag_block;
+    DevBuf<SchurChunk> chunks;
+    DevBuf<SchurBatch> batches;
+    DevBuf<uint32_t> row_ptr, ent_col, ent_blk, blk_row, blk_col;
+
+    // state and work buffers
+    DevBuf<double> cams[2], pts[2];
+    int cur = 0;
+    DevBuf<double> jc, jpr, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
+    DevBuf<double> lin_resid, lin_work, dense;
+    DevBuf<double> reduce_own;          // library-owned reduce buffer
+    double* reduce = nullptr;           // [S blocks | rhs | diagB | gc_red | tail(4)] [scalars(SC_COUNT)]
+    uint64_t reduce_main = 0;           // f64 in the per-iteration system payload
+    uint64_t reduce_count = 0;          // reduce_main + SC_COUNT: everything an all-reduce may touch
+    double* host_scal = nullptr;        // pinned, SC_COUNT + 4
+
+    // multi-GPU
+    soslam_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    int rank = 0, world = 1;
+
+    // trust region
+    double radius = 0.0, decrease_factor = 2.0, x_cost = 0.0;
+    bool linearized = false, scale_init = false;
+    int invalid_run = 0;
+    std::vector<soslam_ba_iteration> log;
+
+    // profiling
+    std::vector<hipEvent_t> ev_pool;
+    struct StageMark { int stage; size_t e0, e1; };
+    std::vector<StageMark> marks;
+    size_t ev_used = 0;
+
+    double* S() const { return reduce; }
+    double* rhs() const { return reduce + (size_t)n_blocks * 36; }
+    double* diagB() const { return rhs() + (size_t)n_free * 6; }
+    double* gc_red() const { return diagB() + (size_t)n_free * 6; }
+    double* tail() const { return gc_red() + (size_t)n_free * 6; }
+    double* scalp() const { return reduce + reduce_main; }
+
+    ~soslam_ba()
+    {
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+        if (host_scal) (void)hipHostFree(host_scal);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+LmDiag lm_diag(const soslam_ba* h, double radius) { return LmDiag{radius, h->opt.min_lm_diagonal, h->opt.max_lm_diagonal}; }
+
+// ---- profiling marks ---------------------------------------------------------------------------------
+
+struct StageScope {
+    soslam_ba* h;
+    int stage;
+    size_t idx = 0;
+    bool on;
+    StageScope(soslam_ba* h_, int stage_) : h(h_), stage(stage_), on(h_->opt.profile_stages != 0)
+    {
+        if (!on) return;
+        while (h->ev_pool.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+            h->ev_pool.push_back(e);
+        }
+        idx = h->ev_used;
+        h->ev_used += 2;
+        (void)hipEventRecord(h->ev_pool[idx], h->stream);
+    }
+    ~StageScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(h->ev_pool[idx + 1], h->stream);
+        h->marks.push_back({stage, idx, idx + 1});
+    }
+};
+
+void collect_stage_times(soslam_ba* h, soslam_ba_summary* s)
+{
+    if (!h->opt.profile_stages || !s) { h->marks.clear(); h->ev_used = 0; return; }
+    (void)hipStreamSynchronize(h->stream);
+    for (const auto& m : h->marks) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[m.e0], h->ev_pool[m.e1]) == hipSuccess) {
+            s->stage_ms[m.stage] += ms;
+            s->stage_calls[m.stage]++;
+        }
+    }
+    h->marks.clear();
+    h->ev_used = 0;
+}
+
+// ---- index construction ------------------------------------------------------------------------------
+
+int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, const uint32_t* ocam,
+                  const uint32_t* opt_, const float* ouv, const uint8_t* fixed)
+{
+    const double t0 = now_sec();
+    hipStream_t s = h->stream;
+    for (uint32_t k = 0; k < n_obs; k++)
+        if (ocam[k] >= n_cam || opt_[k] >= n_pt) {
+            set_last_error("observation %u refers to camera %u / point %u out of range", k, ocam[k], opt_[k]);
+            return SOSLAM_ERR_INVALID_ARGUMENT;
+        }
+    h->n_cam = n_cam; h->n_pt = n_pt; h->n_obs = n_obs;
+
+    // free-camera numbering
+    h->h_cam_free.assign(n_cam, -1);
+    uint32_t nf = 0;
+    for (uint32_t c = 0; c < n_cam; c++)
+        if (!(fixed && fixed[c])) h->h_cam_free[c] = (int32_t)nf++;
+    h->n_free = nf;
+
+    // internal point order: by (first camera, last camera, caller id) so that neighbouring points share
+    // their camera window (the Schur kernel's chunks) and a camera bucket reads near-contiguous points
+    std::vector<uint32_t> pmin(n_pt, UINT32_MAX), pmax(n_pt, 0), pcnt(n_pt, 0);
+    for (uint32_t k = 0; k < n_obs; k++) {
+        const uint32_t p = opt_[k], c = ocam[k];
+        pmin[p] = std::min(pmin[p], c); pmax[p] = std::max(pmax[p], c); pcnt[p]++;
+    }
+    for (uint32_t p = 0; p < n_pt; p++)
+        if (pcnt[p] > (uint32_t)kBatchObs) {
+            set_last_error("point %u has %u observations; this build supports up to %d per point", p, pcnt[p], kBatchObs);
+            return SOSLAM_ERR_INVALID_ARGUMENT;
+        }
+    h->pt_int2user.resize(n_pt);
+    std::iota(h->pt_int2user.begin(), h->pt_int2user.end(), 0u);
+    std::sort(h->pt_int2user.begin(), h->pt_int2user.end(), [&](uint32_t a, uint32_t b) {
+        if (pmin[a] != pmin[b]) return pmin[a] < pmin[b];
+        if (pmax[a] != pmax[b]) return pmax[a] < pmax[b];
+        return a < b;
+    });
+    h->pt_user2int.resize(n_pt);
+    for (uint32_t i = 0; i < n_pt; i++) h->pt_user2int[h->pt_int2user[i]] = i;
+
+    // camera-major observation order: (camera, internal point)
+    h->obs_int2user.resize(n_obs);
+    std::iota(h->obs_int2user.begin(), h->obs_int2user.end(), 0u);
+    std::sort(h->obs_int2user.begin(), h->obs_int2user.end(), [&](uint32_t a, uint32_t b) {
+        if (ocam[a] != ocam[b]) return ocam[a] < ocam[b];
+        const uint32_t pa = h->pt_user2int[opt_[a]], pb = h->pt_user2int[opt_[b]];
+        if (pa != pb) return pa < pb;
+        return a < b;
+    });
+    std::vector<float4> uv(n_obs);
+    std::vector<uint32_t> v_obs_pt(n_obs), v_obs_cam(n_obs);
+    std::vector<uint32_t> cam_start(n_cam + 1, 0);
+    for (uint32_t i = 0; i < n_obs; i++) {
+        const uint32_t k = h->obs_int2user[i];
+        uv[i] = make_float4(ouv[4 * (size_t)k], ouv[4 * (size_t)k + 1], ouv[4 * (size_t)k + 2], ouv[4 * (size_t)k + 3]);
+        v_obs_pt[i] = h->pt_user2int[opt_[k]];
+        v_obs_cam[i] = ocam[k];
+        cam_start[ocam[k] + 1]++;
+    }
+    for (uint32_t c = 0; c < n_cam; c++) cam_start[c + 1] += cam_start[c];
+
+    // tiles: <= kTileObs observations of one camera each
+    std::vector<Tile> tiles;
+    std::vector<uint32_t> cam_tile_start(n_cam + 1, 0);
+    for (uint32_t c = 0; c < n_cam; c++) {
+        cam_tile_start[c] = (uint32_t)tiles.size();
+        for (uint32_t b = cam_start[c]; b < cam_start[c + 1]; b += kTileObs)
+            tiles.push_back(Tile{c, b, std::min<uint32_t>(kTileObs, cam_start[c + 1] - b), 0});
+    }
+    cam_tile_start[n_cam] = (uint32_t)tiles.size();
+    h->n_tiles = (uint32_t)tiles.size();
+
+    // point-major lists (camera ascending inside a point because the scan is camera-major)
+    std::vector<uint32_t> pt_start(n_pt + 1, 0), pt_obs(n_obs), q_pt(n_obs);
+    for (uint32_t i = 0; i < n_obs; i++) pt_start[v_obs_pt[i] + 1]++;
+    for (uint32_t p = 0; p < n_pt; p++) pt_start[p + 1] += pt_start[p];
+    {
+        std::vector<uint32_t> fill(pt_start.begin(), pt_start.end() - 1);
+        for (uint32_t i = 0; i < n_obs; i++) {
+            const uint32_t q = fill[v_obs_pt[i]]++;
+            pt_obs[q] = i;
+            q_pt[q] = v_obs_pt[i];
+        }
+    }
+
+    // block-sparse pattern of the reduced camera matrix: pairs of free cameras that share a point
+    std::vector<std::vector<uint32_t>> rows(nf);
+    uint32_t max_track = 0;
+    {
+        std::vector<uint32_t> fc;
+        for (uint32_t f = 0; f < nf; f++) rows[f].push_back(f);
+        for (uint32_t p = 0; p < n_pt; p++) {
+            fc.clear();
+            for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
+                const int32_t f = h->h_cam_free[v_obs_cam[pt_obs[q]]];
+                if (f >= 0 && (fc.empty() || fc.back() != (uint32_t)f)) fc.push_back((uint32_t)f);
+            }
+            max_track = std::max<uint32_t>(max_track, (uint32_t)fc.size());
+            for (size_t a = 0; a < fc.size(); a++)
+                for (size_t b = a + 1; b < fc.size(); b++) rows[fc[a]].push_back(fc[b]);
+        }
+        for (const auto& pr : h->covis) {
+            if (pr.first >= n_cam || pr.second >= n_cam) {
+                set_last_error("covisibility pair (%u, %u) out of range", pr.first, pr.second);
+                return SOSLAM_ERR_INVALID_ARGUMENT;
+            }
+            const int32_t fa = h->h_cam_free[pr.first], fb = h->h_cam_free[pr.second];
+            if (fa < 0 || fb < 0) continue;
+            rows[std::min(fa, fb)].push_back((uint32_t)std::max(fa, fb));
+        }
+        for (auto& r : rows) {
+            std::sort(r.begin(), r.end());
+            r.erase(std::unique(r.begin(), r.end()), r.end());
+        }
+    }
+    if (max_track > 32) {
+        set_last_error("a point is observed by %u free cameras; this build supports tracks up to 32", max_track);
+        return SOSLAM_ERR_INVALID_ARGUMENT;
+    }
+    h->kmax = max_track > 16 ? 32 : 16;
+    std::vector<uint32_t> row_first(nf + 1, 0);
+    for (uint32_t f = 0; f < nf; f++) row_first[f + 1] = row_first[f] + (uint32_t)rows[f].size();
+    h->n_blocks = row_first[nf];
+    h->h_blk_row.resize(h->n_blocks); h->h_blk_col.resize(h->n_blocks);
+    std::vector<int32_t> diag_block(nf);
+    for (uint32_t f = 0; f < nf; f++)
+        for (size_t e = 0; e < rows[f].size(); e++) {
+            const uint32_t b = row_first[f] + (uint32_t)e;
+            h->h_blk_row[b] = f; h->h_blk_col[b] = rows[f][e];
+            if (rows[f][e] == f) diag_block[f] = (int32_t)b;
+        }
+    auto find_block = [&](uint32_t i, uint32_t j) -> int32_t {
+        const auto& r = rows[i];
+        auto it = std::lower_bound(r.begin(), r.end(), j);
+        if (it == r.end() || *it != j) return -1;
+        return (int32_t)(row_first[i] + (uint32_t)(it - r.begin()));
+    };
+    // full row lists (both triangles) for the matrix-vector product
+    std::vector<uint32_t> row_ptr(nf + 1, 0), ent_col, ent_blk;
+    std::vector<uint8_t> ent_trans;
+    {
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> full(nf);  // (col, blk | trans<<31)
+        for (uint32_t b = 0; b < h->n_blocks; b++) {
+            const uint32_t i = h->h_blk_row[b], j = h->h_blk_col[b];
+            full[i].push_back({j, b});
+            if (i != j) full[j].push_back({i, b | 0x80000000u});
+        }
+        for (uint32_t f = 0; f < nf; f++) {
+            std::sort(full[f].begin(), full[f].end());
+            row_ptr[f + 1] = row_ptr[f] + (uint32_t)full[f].size();
+            for (auto& e : full[f]) {
+                ent_col.push_back(e.first);
+                ent_blk.push_back(e.second & 0x7FFFFFFFu);
+                ent_trans.push_back((uint8_t)(e.second >> 31));
+            }
+        }
+    }
+
+    // Schur chunks: consecutive points whose free cameras fit kmax local slots; batches of <= 128 obs
+    const int K = h->kmax, NPAIR = K * (K + 1) / 2;
+    const uint32_t chunk_pts_max = std::max<uint32_t>(32, std::min<uint32_t>(1024, n_pt / 512 + 1));
+    std::vector<SchurChunk> chunks;
+    std::vector<SchurBatch> batches;
+    std::vector<int32_t> chunk_blocks, chunk_cams;
+    std::vector<uint8_t> q_slot(n_obs, 255);
+    {
+        std::vector<uint32_t> local, merged, fc;
+        uint32_t chunk_p0 = 0;
+        auto close_chunk = [&](uint32_t p_end) {
+            if (p_end == chunk_p0) return;
+            SchurChunk ch{};
+            ch.batch_begin = (uint32_t)batches.size();
+            ch.n_local = (uint32_t)local.size();
+            uint32_t bp = chunk_p0;
+            while (bp < p_end) {
+                uint32_t be = bp, nq = 0;
+                while (be < p_end && (be - bp) < (uint32_t)kBatchPts && nq + (pt_start[be + 1] - pt_start[be]) <= (uint32_t)kBatchObs) {
+                    nq += pt_start[be + 1] - pt_start[be];
+                    be++;
+                }
+                if (be == bp) be = bp + 1;  // single point wider than a batch cannot happen (track <= 32 + fixed)
+                batches.push_back(SchurBatch{pt_start[bp], pt_start[be], bp, be});
+                bp = be;
+            }
+            ch.batch_end = (uint32_t)batches.size();
+            for (uint32_t q = pt_start[chunk_p0]; q < pt_start[p_end]; q++) {
+                const int32_t f = h->h_cam_free[v_obs_cam[pt_obs[q]]];
+                if (f < 0) continue;
+                q_slot[q] = (uint8_t)(std::lower_bound(local.begin(), local.end(), (uint32_t)f) - local.begin());
+            }
+            const size_t cb = chunk_blocks.size(), cc = chunk_cams.size();
+            chunk_blocks.resize(cb + NPAIR, -1);
+            chunk_cams.resize(cc + K, -1);
+            int pair = 0;
+            for (int a = 0; a < K; a++) {
+                if (a < (int)local.size()) chunk_cams[cc + a] = (int32_t)local[a];
+                for (int b = a; b < K; b++, pair++)
+                    if (b < (int)local.size()) chunk_blocks[cb + pair] = find_block(local[a], local[b]);
+            }
+            chunks.push_back(ch);
+            chunk_p0 = p_end;
+            local.clear();
+        };
+        for (uint32_t p = 0; p < n_pt; p++) {
+            fc.clear();
+            for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
+                const int32_t f = h->h_cam_free[v_obs_cam[pt_obs[q]]];
+                if (f >= 0 && (fc.empty() || fc.back() != (uint32_t)f)) fc.push_back((uint32_t)f);
+            }
+            merged.clear();
+            std::set_union(local.begin(), local.end(), fc.begin(), fc.end(), std::back_inserter(merged));
+            if ((int)merged.size() > K || p - chunk_p0 >= chunk_pts_max) {
+                close_chunk(p);
+                merged = fc;
+            }
+            local = merged;
+        }
+        close_chunk(n_pt);
+    }
+    h->n_chunks = (uint32_t)chunks.size();
+    h->n_batches = (uint32_t)batches.size();
+    h->n_point_blocks = div_up(n_pt, kPointBlock);
+
+    // solver choice
+    h->solver = h->opt.linear_solver;
+    if (h->solver == SOSLAM_SOLVER_AUTO) h->solver = (nf * 6 <= (uint32_t)kDenseAutoLimit) ? SOSLAM_SOLVER_DENSE_CHOLESKY : SOSLAM_SOLVER_PCG;
+
+    // uploads
+    SOSLAM_CHECK(h->uv.upload(uv, s));
+    SOSLAM_CHECK(h->obs_pt.upload(v_obs_pt, s));
+    SOSLAM_CHECK(h->obs_cam.upload(v_obs_cam, s));
+    SOSLAM_CHECK(h->tiles.upload(tiles, s));
+    SOSLAM_CHECK(h->cam_tile_start.upload(cam_tile_start, s));
+    SOSLAM_CHECK(h->cam_free.upload(h->h_cam_free, s));
+    SOSLAM_CHECK(h->pt_start.upload(pt_start, s));
+    SOSLAM_CHECK(h->pt_obs.upload(pt_obs, s));
+    SOSLAM_CHECK(h->q_pt.upload(q_pt, s));
+    SOSLAM_CHECK(h->q_slot.upload(q_slot, s));
+    SOSLAM_CHECK(h->chunks.upload(chunks, s));
+    SOSLAM_CHECK(h->batches.upload(batches, s));
+    SOSLAM_CHECK(h->chunk_blocks.upload(chunk_blocks, s));
+    SOSLAM_CHECK(h->chunk_cams.upload(chunk_cams, s));
+    SOSLAM_CHECK(h->diag_block.upload(diag_block, s));
+    SOSLAM_CHECK(h->row_ptr.upload(row_ptr, s));
+    SOSLAM_CHECK(h->ent_col.upload(ent_col, s));
+    SOSLAM_CHECK(h->ent_blk.upload(ent_blk, s));
+    SOSLAM_CHECK(h->ent_trans.upload(ent_trans, s));
+    SOSLAM_CHECK(h->blk_row.upload(h->h_blk_row, s));
+    SOSLAM_CHECK(h->blk_col.upload(h->h_blk_col, s));
+
+    // work buffers
+    for (int i = 0; i < 2; i++) {
+        SOSLAM_CHECK(h->cams[i].alloc((size_t)n_cam * 6));
+        SOSLAM_CHECK(h->pts[i].alloc((size_t)n_pt * 3));
+    }
+    SOSLAM_CHECK(h->jc.alloc((size_t)n_obs * kJcRow));
+    SOSLAM_CHECK(h->jpr.alloc((size_t)n_obs * kJprRow));
+    SOSLAM_CHECK(h->tile_part.alloc((size_t)h->n_tiles * kTileVals));
+    SOSLAM_CHECK(h->cost_part.alloc(h->n_tiles));
+    SOSLAM_CHECK(h->C.alloc((size_t)n_pt * 6));
+    SOSLAM_CHECK(h->gp.alloc((size_t)n_pt * 3));
+    SOSLAM_CHECK(h->sp.alloc((size_t)n_pt * 3));
+    SOSLAM_CHECK(h->Cinv.alloc((size_t)n_pt * 6));
+    SOSLAM_CHECK(h->B.alloc((size_t)nf * 36));
+    SOSLAM_CHECK(h->gc.alloc((size_t)nf * 6));
+    SOSLAM_CHECK(h->sc.alloc((size_t)nf * 6));
+    SOSLAM_CHECK(h->lc.alloc((size_t)nf * 6));
+    SOSLAM_CHECK(h->dc_free.alloc((size_t)nf * 6));
+    SOSLAM_CHECK(h->dc_full.alloc((size_t)n_cam * 6));
+    SOSLAM_CHECK(h->dp.alloc((size_t)n_pt * 3));
+    SOSLAM_CHECK(h->part.alloc((size_t)h->n_point_blocks * 5));
+    SOSLAM_CHECK(h->lin_resid.alloc((size_t)nf * 6));
+    SOSLAM_CHECK(h->lin_work.alloc(pcg_work_count(nf)));
+    SOSLAM_CHECK(h->B.zero(s)); SOSLAM_CHECK(h->gc.zero(s)); SOSLAM_CHECK(h->dc_free.zero(s)); SOSLAM_CHECK(h->Cinv.zero(s));
+    SOSLAM_CHECK(h->lin_resid.zero(s));
+    if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
+        const size_t n6 = (size_t)nf * 6;
+        SOSLAM_CHECK(h->dense.alloc(n6 * n6 + (size_t)div_up(n6, 32) * 32 * 32 + 1024));
+    } else {
+        h->dense.release();
+    }
+    h->reduce_main = (uint64_t)h->n_blocks * 36 + (uint64_t)nf * 18 + 4;
+    h->reduce_count = h->reduce_main + SC_COUNT;
+    SOSLAM_CHECK(h->reduce_own.alloc(h->reduce_count));
+    SOSLAM_CHECK(h->reduce_own.zero(s));
+    h->reduce = h->reduce_own.p;
+    if (!h->host_scal) SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_scal), sizeof(double) * (SC_COUNT + 4), hipHostMallocDefault));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    h->have_problem = true;
+    h->have_state = false;
+    h->setup_seconds = now_sec() - t0;
+    return SOSLAM_OK;
+}
+
+// ---- device pipeline ---------------------------------------------------------------------------------
+
+// residuals, Jacobians and the J^T J / J^T r blocks at the current state
+int linearize(soslam_ba* h)
+{
+    hipStream_t s = h->stream;
+    {
+        StageScope sc(h, SOSLAM_STAGE_LINEARIZE);
+        launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->cams[h->cur].p, h->pts[h->cur].p, h->cam_free.p,
+                         h->proj, h->opt.huber_delta, h->jc.p, h->jpr.p, h->tile_part.p);
+        launch_cam_reduce(s, h->n_cam, h->cam_tile_start.p, h->cam_free.p, h->tile_part.p, h->B.p, h->gc.p);
+        launch_sum_strided(s, h->tile_part.p, h->n_tiles, kTileVals, 27, 0.5, h->scalp() + SC_COST_X);
+    }
+    {
+        StageScope sc(h, SOSLAM_STAGE_POINT_REDUCE);
+        launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->jpr.p, h->C.p, h->gp.p);
+        if (!h->scale_init) launch_point_scale(s, h->n_pt, h->C.p, h->opt.jacobi_scaling, h->sp.p);
+    }
+    SOSLAM_HIP_CHECK(hipGetLastError());
+    h->linearized = true;
+    return SOSLAM_OK;
+}
+
+int do_allreduce(soslam_ba* h, double* buf, uint64_t count, int op)
+{
+    if (h->world <= 1 || !h->allreduce) return SOSLAM_OK;
+    if (h->allreduce(h->allreduce_user, buf, count, op, h->stream) != 0) {
+        set_last_error("all-reduce callback failed (rank %d, %llu f64)", h->rank, (unsigned long long)count);
+        return SOSLAM_ERR_COMM;
+    }
+    return SOSLAM_OK;
+}
+
+BsrView bsr_view(const soslam_ba* h)
+{
+    return BsrView{h->n_free, h->row_ptr.p, h->ent_col.p, h->ent_blk.p, h->ent_trans.p, h->diag_block.p, h->S()};
+}
+
+// one trust-region step from the current linearisation: reduced system, solve, candidate, candidate cost
+int take_step(soslam_ba* h, double radius)
+{
+    hipStream_t s = h->stream;
+    const LmDiag lm = lm_diag(h, radius);
+    {
+        StageScope sc(h, SOSLAM_STAGE_SCHUR);
+        SOSLAM_HIP_CHECK(hipMemsetAsync(h->reduce, 0, sizeof(double) * h->reduce_main, s));
+        launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_blocks.p, h->chunk_cams.p, h->pt_obs.p,
+                     h->q_pt.p, h->q_slot.p, h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->S(), h->rhs(),
+                     h->scalp());
+        launch_schur_finalize(s, h->n_free, h->B.p, h->gc.p, h->diag_block.p, h->S(), h->rhs(), h->diagB(), h->gc_red());
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->tail(), h->scalp() + SC_COST_X, sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    {
+        StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
+        SOSLAM_CHECK(do_allreduce(h, h->reduce, h->reduce_main, SOSLAM_REDUCE_SUM));
+    }
+    {
+        StageScope sc(h, SOSLAM_STAGE_SOLVE);
+        launch_cam_damp(s, h->n_free, h->diagB(), h->sc.p, h->scale_init ? 0 : 1, h->opt.jacobi_scaling, lm, h->diag_block.p,
+                        h->S(), h->lc.p);
+        h->scale_init = true;
+        const double* resid = nullptr;
+        if (h->n_free) {
+            if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
+                launch_bsr_to_dense(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->dense.p);
+                launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
+            } else {
+                launch_pcg(s, bsr_view(h), h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance,
+                           h->opt.pcg_max_iterations, h->scalp());
+                resid = h->lin_resid.p;
+            }
+        }
+        launch_cam_update(s, h->n_cam, h->cam_free.p, h->cams[h->cur].p, h->dc_free.p, h->lc.p, h->gc_red(), resid,
+                          h->cams[h->cur ^ 1].p, h->dc_full.p, h->scalp());
+    }
+    {
+        StageScope sc(h, SOSLAM_STAGE_BACKSUB);
+        launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->obs_cam.p, h->jc.p, h->jpr.p, h->dc_full.p, h->Cinv.p, h->C.p,
+                       h->gp.p, h->sp.p, h->pts[h->cur].p, lm, h->opt.lower_bound, h->opt.upper_bound, h->pts[h->cur ^ 1].p,
+                       h->dp.p, h->part.p);
+        launch_sum5(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS);
+    }
+    {
+        StageScope sc(h, SOSLAM_STAGE_COST);
+        launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->cams[h->cur ^ 1].p, h->pts[h->cur ^ 1].p, h->proj,
+                    h->opt.huber_delta, h->cost_part.p);
+        launch_sum_strided(s, h->cost_part.p, h->n_tiles, 1, 0, 0.5, h->scalp() + SC_CAND_COST);
+    }
+    {
+        StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
+        SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_CAND_COST, 5, SOSLAM_REDUCE_SUM));
+        if (h->opt.check_termination) SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_GMAX_PTS, 1, SOSLAM_REDUCE_MAX));
+    }
+    {
+        StageScope sc(h, SOSLAM_STAGE_SYNC);
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_scal, h->scalp(), sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_scal + SC_COUNT, h->tail(), sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    SOSLAM_HIP_CHECK(hipGetLastError());
+    return SOSLAM_OK;
+}
+
+struct StepScalars {
+    double x_cost, cand_cost, mcc, step_norm, x_norm, gdot, gmax;
+    int lin_iters, lin_status, schur_status;
+};
+
+StepScalars read_scalars(const soslam_ba* h)
+{
+    const double* v = h->host_scal;
+    StepScalars r;
+    r.x_cost = v[SC_COUNT];
+    r.cand_cost = v[SC_CAND_COST];
+    r.mcc = v[SC_MCC_PTS] + v[SC_MCC_CAM];
+    r.step_norm = std::sqrt(v[SC_STEP2_PTS] + v[SC_STEP2_CAM]);
+    r.x_norm = std::sqrt(v[SC_X2_PTS] + v[SC_X2_CAM]);
+    r.gdot = v[SC_GDOT_PTS] + v[SC_GDOT_CAM];
+    r.gmax = std::max(v[SC_GMAX_PTS], v[SC_GMAX_CAM]);
+    r.lin_iters = (int)v[SC_LIN_ITERS];
+    r.lin_status = (int)v[SC_LIN_STATUS];
+    r.schur_status = (int)v[SC_SCHUR_STATUS];
+    return r;
+}
+
+// The Levenberg-Marquardt loop.  fixed_count >= 0: exactly that many iterations, no termination tests.
+int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
+{
+    if (!h->have_problem || !h->have_state || !h->have_proj) {
+        set_last_error("solve called before set_projection / set_problem / set_state");
+        return SOSLAM_ERR_STATE;
+    }
+    const soslam_ba_options& o = h->opt;
+    const bool check = fixed_count < 0 && o.check_termination;
+    const int max_it = fixed_count >= 0 ? fixed_count : o.max_iterations;
+    soslam_ba_summary sum{};
+    sum.linear_solver = h->solver;
+    sum.setup_seconds = h->setup_seconds;
+    sum.termination = SOSLAM_TERM_MAX_ITERATIONS;
+    const double t0 = now_sec();
+    h->log.clear();
+    hipStream_t s = h->stream;
+
+    if (!h->linearized) SOSLAM_CHECK(linearize(h));
+    bool have_initial = false;
+    int it = 0;
+    while (true) {
+        if (it >= max_it) { sum.termination = SOSLAM_TERM_MAX_ITERATIONS; break; }
+        if (check && h->radius < o.min_radius) { sum.termination = SOSLAM_TERM_MIN_RADIUS; break; }
+        if (check && o.max_solver_time_seconds > 0.0 && now_sec() - t0 > o.max_solver_time_seconds) { sum.termination = SOSLAM_TERM_TIME; break; }
+        SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp() + SC_SCHUR_STATUS, 0, sizeof(double), s));
+        SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp() + SC_LIN_ITERS, 0, 3 * sizeof(double), s));
+        const double radius = h->radius;
+        SOSLAM_CHECK(take_step(h, radius));
+        const StepScalars sc = read_scalars(h);
+        h->x_cost = sc.x_cost;
+        if (!have_initial) {
+            have_initial = true;
+            sum.initial_cost = sc.x_cost;
+            if (!std::isfinite(sc.x_cost)) {
+                set_last_error("non-finite cost at the initial point");
+                return SOSLAM_ERR_NON_FINITE;
+            }
+            soslam_ba_iteration e{};
+            e.cost = sc.x_cost; e.radius = radius; e.gradient_max_norm = sc.gmax; e.accepted = 1; e.valid = 1;
+            h->log.push_back(e);
+        } else if (!h->log.empty() && h->log.back().accepted) {
+            h->log.back().gradient_max_norm = sc.gmax;  // gradient at the point the last accepted step reached
+        }
+        if (check && sc.gmax <= o.gradient_tolerance) { sum.termination = SOSLAM_TERM_GRADIENT_TOLERANCE; break; }
+        it++;
+        soslam_ba_iteration e{};
+        e.cost = sc.x_cost; e.radius = radius; e.gradient_max_norm = sc.gmax;
+        e.model_cost_change = sc.mcc; e.linear_iterations = sc.lin_iters;
+        sum.linear_iterations += sc.lin_iters;
+        const bool lin_ok = sc.schur_status == 0 && sc.lin_status == 0 && std::isfinite(sc.mcc);
+        if (!lin_ok || !(sc.mcc > 0.0)) {
+            e.valid = 0;
+            h->log.push_back(e);
+            if (check && ++h->invalid_run >= 5) { sum.termination = SOSLAM_TERM_INVALID_STEPS; break; }
+            h->radius /= h->decrease_factor;
+            h->decrease_factor *= 2.0;
+            if (o.verbose) printf("%4d  cost %.9e  invalid step (model change %.3e)  radius %.3e\n", it, sc.x_cost, sc.mcc, radius);
+            continue;
+        }
+        h->invalid_run = 0;
+        e.valid = 1;
+        e.candidate_cost = sc.cand_cost;
+        e.step_norm = sc.step_norm;
+        if (!(sc.cand_cost <= sc.x_cost + 1e-4 * sc.gdot)) sum.armijo_violations++;
+        if (check) {
+            if (sc.step_norm <= o.parameter_tolerance * (sc.x_norm + o.parameter_tolerance)) {
+                h->log.push_back(e);
+                sum.termination = SOSLAM_TERM_PARAMETER_TOLERANCE;
+                break;
+            }
+            if (std::fabs(sc.x_cost - sc.cand_cost) <= o.function_tolerance * sc.x_cost) {
+                h->log.push_back(e);
+                sum.termination = SOSLAM_TERM_FUNCTION_TOLERANCE;
+                break;
+            }
+        }
+        const double rel = (sc.x_cost - sc.cand_cost) / sc.mcc;
+        e.relative_decrease = rel;
+        if (rel > o.min_relative_decrease) {
+            h->cur ^= 1;
+            h->x_cost = sc.cand_cost;
+            SOSLAM_CHECK(linearize(h));
+            double f = 1.0 - std::pow(2.0 * rel - 1.0, 3.0);
+            if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+            h->radius = std::min(o.max_radius, h->radius / f);
+            h->decrease_factor = 2.0;
+            e.accepted = 1;
+            e.cost = sc.cand_cost;
+            sum.accepted++;
+        } else {
+            h->radius /= h->decrease_factor;
+            h->decrease_factor *= 2.0;
+        }
+        h->log.push_back(e);
+        if (o.verbose)
+            printf("%4d  cost %.9e  cand %.9e  model %.3e  rho %.3e  |step| %.3e  radius %.3e  lin_it %d  %s\n", it, sc.x_cost,
+                   sc.cand_cost, sc.mcc, rel, sc.step_norm, radius, sc.lin_iters, e.accepted ? "accepted" : "rejected");
+    }
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    sum.iterations = it;
+    sum.final_cost = h->x_cost;
+    if (!have_initial) {
+        // zero iterations requested: report the cost of the current point
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_scal, h->scalp(), sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        sum.initial_cost = sum.final_cost = h->x_cost = h->host_scal[0];
+    }
+    sum.solve_seconds = now_sec() - t0;
+    collect_stage_times(h, &sum);
+    if (out) *out = sum;
+    return SOSLAM_OK;
+}
+
+}  // namespace
+
+// ---- C ABI -------------------------------------------------------------------------------------------
+
+extern "C" {
+
+const char* soslam_version(void) { return "soslam_ba 0.1.0 (gfx950)"; }
+
+const char* soslam_status_string(int status)
+{
+    switch (status) {
+    case SOSLAM_OK: return "ok";
+    case SOSLAM_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case SOSLAM_ERR_HIP: return "HIP runtime error";
+    case SOSLAM_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case SOSLAM_ERR_NON_FINITE: return "non-finite cost";
+    case SOSLAM_ERR_LINEAR_SOLVER: return "linear solver failure";
+    case SOSLAM_ERR_COMM: return "all-reduce failed";
+    case SOSLAM_ERR_STATE: return "call sequence error";
+    default: return "unknown status";
+    }
+}
+
+const char* soslam_last_error(void) { return g_last_error.c_str(); }
+
+void soslam_ba_options_default(soslam_ba_options* o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->max_iterations = 50;
+    o->check_termination = 1;
+    o->linear_solver = SOSLAM_SOLVER_AUTO;
+    o->pcg_max_iterations = 500;
+    o->pcg_tolerance = 1e-10;
+    o->huber_delta = 1.0;
+    o->lower_bound = -10000.0;
+    o->upper_bound = 10000.0;
+    o->initial_radius = 1e4;
+    o->max_radius = 1e16;
+    o->min_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->parameter_tolerance = 1e-8;
+    o->function_tolerance = 1e-16;
+    o->gradient_tolerance = 1e-16;
+    o->max_solver_time_seconds = 0.0;
+    o->jacobi_scaling = 1;
+    o->verbose = 0;
+    o->device = -1;
+    o->profile_stages = 0;
+    o->stream = nullptr;
+}
+
+int soslam_ba_create(const soslam_ba_options* opts, soslam_ba** out)
+{
+    if (!out) return SOSLAM_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        set_last_error("no HIP device visible: the bundle-adjustment backend has no CPU fallback");
+        return SOSLAM_ERR_NO_DEVICE;
+    }
+    std::unique_ptr<soslam_ba> h(new soslam_ba());
+    if (opts) h->opt = *opts; else soslam_ba_options_default(&h->opt);
+    if (h->opt.device >= 0) {
+        if (h->opt.device >= n_dev) { set_last_error("device %d out of range (%d visible)", h->opt.device, n_dev); return SOSLAM_ERR_INVALID_ARGUMENT; }
+        SOSLAM_HIP_CHECK(hipSetDevice(h->opt.device));
+    }
+    SOSLAM_HIP_CHECK(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    SOSLAM_HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_last_error("device %d is %s; this library carries gfx950 code objects only", h->device, prop.gcnArchName);
+        return SOSLAM_ERR_NO_DEVICE;
+    }
+    if (h->opt.stream) {
+        h->stream = static_cast<hipStream_t>(h->opt.stream);
+    } else {
+        SOSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    *out = h.release();
+    return SOSLAM_OK;
+}
+
+void soslam_ba_destroy(soslam_ba* h)
+{
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+int soslam_ba_set_projection(soslam_ba* h, const double* pl, const double* pr)
+{
+    if (!h || !pl || !pr) return SOSLAM_ERR_INVALID_ARGUMENT;
+    std::memcpy(h->proj.l, pl, sizeof h->proj.l);
+    std::memcpy(h->proj.r, pr, sizeof h->proj.r);
+    h->have_proj = true;
+    h->linearized = false;
+    return SOSLAM_OK;
+}
+
+int soslam_ba_set_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, const uint32_t* obs_cam,
+                          const uint32_t* obs_pt, const float* obs_uv, const uint8_t* cam_fixed)
+{
+    if (!h || n_cam == 0 || (n_obs && (!obs_cam || !obs_pt || !obs_uv))) return SOSLAM_ERR_INVALID_ARGUMENT;
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    h->have_problem = false;
+    h->linearized = false;
+    return build_problem(h, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_uv, cam_fixed);
+}
+
+int soslam_ba_set_state(soslam_ba* h, const double* poses, const double* points)
+{
+    if (!h || !poses || (h->n_pt && !points)) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_problem) { set_last_error("set_state before set_problem"); return SOSLAM_ERR_STATE; }
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    std::vector<double> p((size_t)h->n_pt * 3);
+    for (uint32_t i = 0; i < h->n_pt; i++) std::memcpy(&p[3 * (size_t)i], points + 3 * (size_t)h->pt_int2user[i], 3 * sizeof(double));
+    h->cur = 0;
+    SOSLAM_HIP_CHECK(hipMemcpyAsync(h->cams[0].p, poses, sizeof(double) * 6 * h->n_cam, hipMemcpyHostToDevice, h->stream));
+    if (h->n_pt) SOSLAM_HIP_CHECK(hipMemcpyAsync(h->pts[0].p, p.data(), sizeof(double) * p.size(), hipMemcpyHostToDevice, h->stream));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->radius = h->opt.initial_radius;
+    h->decrease_factor = 2.0;
+    h->invalid_run = 0;
+    h->linearized = false;
+    h->scale_init = false;
+    h->have_state = true;
+    return SOSLAM_OK;
+}
+
+int soslam_ba_get_state(soslam_ba* h, double* poses, double* points)
+{
+    if (!h) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_state) { set_last_error("get_state before set_state"); return SOSLAM_ERR_STATE; }
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    std::vector<double> c((size_t)h->n_cam * 6), p((size_t)h->n_pt * 3);
+    SOSLAM_HIP_CHECK(hipMemcpyAsync(c.data(), h->cams[h->cur].p, sizeof(double) * c.size(), hipMemcpyDeviceToHost, h->stream));
+    if (h->n_pt) SOSLAM_HIP_CHECK(hipMemcpyAsync(p.data(), h->pts[h->cur].p, sizeof(double) * p.size(), hipMemcpyDeviceToHost, h->stream));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (poses) std::memcpy(poses, c.data(), sizeof(double) * c.size());
+    if (points)
+        for (uint32_t i = 0; i < h->n_pt; i++) std::memcpy(points + 3 * (size_t)h->pt_int2user[i], &p[3 * (size_t)i], 3 * sizeof(double));
+    return SOSLAM_OK;
+}
+
+int soslam_ba_solve(soslam_ba* h, soslam_ba_summary* summary)
+{
+    if (!h) return SOSLAM_ERR_INVALID_ARGUMENT;
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    return run_lm(h, -1, summary);
+}
+
+int soslam_ba_iterate(soslam_ba* h, int32_t n, soslam_ba_summary* summary)
+{
+    if (!h || n < 0) return SOSLAM_ERR_INVALID_ARGUMENT;
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    return run_lm(h, n, summary);
+}
+
+int soslam_ba_get_iteration_log(soslam_ba* h, soslam_ba_iteration* out, int32_t capacity, int32_t* count)
+{
+    if (!h || !count) return SOSLAM_ERR_INVALID_ARGUMENT;
+    *count = (int32_t)h->log.size();
+    if (out) for (int32_t i = 0; i < capacity && i < *count; i++) out[i] = h->log[(size_t)i];
+    return SOSLAM_OK;
+}
+
+int soslam_ba_optimize(const soslam_ba_options* opts, const double* pl, const double* pr, uint32_t n_cam, double* poses,
+                       uint32_t n_pt, double* points, uint32_t n_obs, const uint32_t* obs_cam, const uint32_t* obs_pt,
+                       const float* obs_uv, const uint8_t* cam_fixed, soslam_ba_summary* summary)
+{
+    soslam_ba* h = nullptr;
+    SOSLAM_CHECK(soslam_ba_create(opts, &h));
+    int st = soslam_ba_set_projection(h, pl, pr);
+    if (st == SOSLAM_OK) st = soslam_ba_set_problem(h, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_uv, cam_fixed);
+    if (st == SOSLAM_OK) st = soslam_ba_set_state(h, poses, points);
+    if (st == SOSLAM_OK) st = soslam_ba_solve(h, summary);
+    if (st == SOSLAM_OK) st = soslam_ba_get_state(h, poses, points);
+    soslam_ba_destroy(h);
+    return st;
+}
+
+int soslam_ba_set_allreduce(soslam_ba* h, soslam_allreduce_fn fn, void* user, int32_t rank, int32_t world)
+{
+    if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return SOSLAM_ERR_INVALID_ARGUMENT;
+    h->allreduce = fn; h->allreduce_user = user; h->rank = rank; h->world = world;
+    return SOSLAM_OK;
+}
+
+int soslam_ba_reduce_buffer_count(soslam_ba* h, uint64_t* count)
+{
+    if (!h || !count) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_problem) { set_last_error("reduce_buffer_count before set_problem"); return SOSLAM_ERR_STATE; }
+    *count = h->reduce_count;
+    return SOSLAM_OK;
+}
+
+int soslam_ba_set_reduce_buffer(soslam_ba* h, void* ptr, uint64_t count)
+{
+    if (!h) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_problem) { set_last_error("set_reduce_buffer before set_problem"); return SOSLAM_ERR_STATE; }
+    if (!ptr) { h->reduce = h->reduce_own.p; h->linearized = false; return SOSLAM_OK; }
+    if (count < h->reduce_count) { set_last_error("reduce buffer too small: %llu < %llu f64", (unsigned long long)count, (unsigned long long)h->reduce_count); return SOSLAM_ERR_INVALID_ARGUMENT; }
+    h->reduce = static_cast<double*>(ptr);
+    SOSLAM_HIP_CHECK(hipMemsetAsync(h->reduce, 0, sizeof(double) * h->reduce_count, h->stream));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->linearized = false;
+    return SOSLAM_OK;
+}
+
+int soslam_ba_set_covisibility(soslam_ba* h, uint64_t n_pairs, const uint32_t* cam_a, const uint32_t* cam_b)
+{
+    if (!h || (n_pairs && (!cam_a || !cam_b))) return SOSLAM_ERR_INVALID_ARGUMENT;
+    h->covis.clear();
+    h->covis.reserve(n_pairs);
+    for (uint64_t i = 0; i < n_pairs; i++) h->covis.emplace_back(cam_a[i], cam_b[i]);
+    return SOSLAM_OK;
+}
+
+void soslam_ba_shard_range(uint32_t n_pt, int32_t rank, int32_t world, uint32_t* begin, uint32_t* end)
+{
+    if (world < 1) world = 1;
+    if (begin) *begin = (uint32_t)(((uint64_t)rank * n_pt) / (uint64_t)world);
+    if (end) *end = (uint32_t)(((uint64_t)(rank + 1) * n_pt) / (uint64_t)world);
+}
+
+int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg_ms)
+{
+    if (!h || reps < 1 || !avg_ms) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_problem || !h->have_state || !h->have_proj) { set_last_error("time_kernel needs a problem and a state"); return SOSLAM_ERR_STATE; }
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (!h->linearized) SOSLAM_CHECK(linearize(h));
+    if (kernel == SOSLAM_KERNEL_SCHUR || kernel == SOSLAM_KERNEL_BACKSUB) {
+        // these read the point scales; make sure they exist
+        if (!h->scale_init) launch_point_scale(s, h->n_pt, h->C.p, h->opt.jacobi_scaling, h->sp.p);
+    }
+    const LmDiag lm = lm_diag(h, h->radius > 0 ? h->radius : h->opt.initial_radius);
+    hipEvent_t e0, e1;
+    SOSLAM_HIP_CHECK(hipEventCreate(&e0));
+    SOSLAM_HIP_CHECK(hipEventCreate(&e1));
+    auto once = [&]() {
+        switch (kernel) {
+        case SOSLAM_KERNEL_LINEARIZE:
+            launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->cams[h->cur].p, h->pts[h->cur].p, h->cam_free.p,
+                             h->proj, h->opt.huber_delta, h->jc.p, h->jpr.p, h->tile_part.p);
+            break;
+        case SOSLAM_KERNEL_COST:
+            launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->cams[h->cur].p, h->pts[h->cur].p, h->proj,
+                        h->opt.huber_delta, h->cost_part.p);
+            break;
+        case SOSLAM_KERNEL_POINT_REDUCE:
+            launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->jpr.p, h->C.p, h->gp.p);
+            break;
+        case SOSLAM_KERNEL_SCHUR:
+            launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_blocks.p, h->chunk_cams.p, h->pt_obs.p,
+                         h->q_pt.p, h->q_slot.p, h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->S(), h->rhs(),
+                         h->scalp());
+            break;
+        case SOSLAM_KERNEL_BACKSUB:
+            launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->obs_cam.p, h->jc.p, h->jpr.p, h->dc_full.p, h->Cinv.p,
+                           h->C.p, h->gp.p, h->sp.p, h->pts[h->cur].p, lm, h->opt.lower_bound, h->opt.upper_bound,
+                           h->pts[h->cur ^ 1].p, h->dp.p, h->part.p);
+            break;
+        default: break;
+        }
+    };
+    if (kernel < 0 || kernel > SOSLAM_KERNEL_BACKSUB) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return SOSLAM_ERR_INVALID_ARGUMENT; }
+    if (kernel == SOSLAM_KERNEL_BACKSUB) {
+        SOSLAM_HIP_CHECK(hipMemsetAsync(h->dc_full.p, 0, sizeof(double) * 6 * h->n_cam, s));
+        SOSLAM_HIP_CHECK(hipMemsetAsync(h->reduce, 0, sizeof(double) * h->reduce_main, s));
+        launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_blocks.p, h->chunk_cams.p, h->pt_obs.p, h->q_pt.p,
+                     h->q_slot.p, h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->S(), h->rhs(), h->scalp());
+    }
+    once();  // warm-up
+    SOSLAM_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; i++) once();
+    SOSLAM_HIP_CHECK(hipEventRecord(e1, s));
+    SOSLAM_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    SOSLAM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)reps;
+    // the timed launches may have disturbed the reduce buffer / candidate; force a clean re-linearisation
+    h->linearized = false;
+    SOSLAM_HIP_CHECK(hipGetLastError());
+    return SOSLAM_OK;
+}
+
+int soslam_ba_debug_step(soslam_ba* h, double radius)
+{
+    if (!h || !(radius > 0.0)) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_problem || !h->have_state || !h->have_proj) { set_last_error("debug_step needs a problem and a state"); return SOSLAM_ERR_STATE; }
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    h->scale_init = false;  // scaling from THIS linearisation, as on the first iteration
+    SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp(), 0, sizeof(double) * SC_COUNT, h->stream));
+    SOSLAM_CHECK(linearize(h));
+    SOSLAM_CHECK(take_step(h, radius));
+    return SOSLAM_OK;
+}
+
+int soslam_ba_debug_read(soslam_ba* h, int32_t what, void* dst, uint64_t bytes)
+{
+    if (!h || !dst) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_problem) { set_last_error("debug_read before set_problem"); return SOSLAM_ERR_STATE; }
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    auto need = [&](uint64_t n) -> int {
+        if (bytes < n) { set_last_error("debug_read: buffer of %llu bytes, %llu needed", (unsigned long long)bytes, (unsigned long long)n); return SOSLAM_ERR_INVALID_ARGUMENT; }
+        return SOSLAM_OK;
+    };
+    double* out = static_cast<double*>(dst);
+    const size_t n_obs = h->n_obs;
+    switch (what) {
+    case SOSLAM_DBG_RESIDUALS:
+    case SOSLAM_DBG_JAC_POINT: {
+        const size_t w = what == SOSLAM_DBG_RESIDUALS ? 4 : 12, off = what == SOSLAM_DBG_RESIDUALS ? 12 : 0;
+        SOSLAM_CHECK(need(n_obs * w * sizeof(double)));
+        std::vector<double> tmp(n_obs * kJprRow);
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->jpr.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < n_obs; i++) std::memcpy(out + w * h->obs_int2user[i], &tmp[i * kJprRow + off], w * sizeof(double));
+        return SOSLAM_OK;
+    }
+    case SOSLAM_DBG_JAC_CAM: {
+        SOSLAM_CHECK(need(n_obs * 24 * sizeof(double)));
+        std::vector<double> tmp(n_obs * kJcRow);
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->jc.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < n_obs; i++) std::memcpy(out + 24 * (size_t)h->obs_int2user[i], &tmp[i * kJcRow], 24 * sizeof(double));
+        return SOSLAM_OK;
+    }
+    case SOSLAM_DBG_COST:
+        SOSLAM_CHECK(need(sizeof(double)));
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(out, h->scalp() + SC_COST_X, sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        return SOSLAM_OK;
+    case SOSLAM_DBG_S_DENSE: {
+        const size_t n6 = (size_t)h->n_free * 6;
+        SOSLAM_CHECK(need(n6 * n6 * sizeof(double)));
+        std::vector<double> blk((size_t)h->n_blocks * 36);
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(blk.data(), h->S(), blk.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        std::memset(out, 0, n6 * n6 * sizeof(double));
+        for (uint32_t b = 0; b < h->n_blocks; b++)
+            for (int a = 0; a < 6; a++)
+                for (int c = 0; c < 6; c++) {
+                    const size_t i = 6 * (size_t)h->h_blk_row[b] + a, j = 6 * (size_t)h->h_blk_col[b] + c;
+                    out[i * n6 + j] = blk[36 * (size_t)b + a * 6 + c];
+                    out[j * n6 + i] = blk[36 * (size_t)b + a * 6 + c];
+                }
+        return SOSLAM_OK;
+    }
+    case SOSLAM_DBG_RHS:
+        SOSLAM_CHECK(need((size_t)h->n_free * 6 * sizeof(double)));
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(out, h->rhs(), (size_t)h->n_free * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        return SOSLAM_OK;
+    case SOSLAM_DBG_STEP_CAM:
+        SOSLAM_CHECK(need((size_t)h->n_cam * 6 * sizeof(double)));
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(out, h->dc_full.p, (size_t)h->n_cam * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        return SOSLAM_OK;
+    case SOSLAM_DBG_STEP_POINT: {
+        SOSLAM_CHECK(need((size_t)h->n_pt * 3 * sizeof(double)));
+        std::vector<double> tmp((size_t)h->n_pt * 3);
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->dp.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < h->n_pt; i++) std::memcpy(out + 3 * (size_t)h->pt_int2user[i], &tmp[3 * (size_t)i], 3 * sizeof(double));
+        return SOSLAM_OK;
+    }
+    case SOSLAM_DBG_STEP_SCALARS: {
+        SOSLAM_CHECK(need(4 * sizeof(double)));
+        const StepScalars sc = read_scalars(h);
+        out[0] = sc.x_cost; out[1] = sc.mcc; out[2] = sc.cand_cost; out[3] = sc.step_norm;
+        return SOSLAM_OK;
+    }
+    default:
+        return SOSLAM_ERR_INVALID_ARGUMENT;
+    }
+}
+
+void soslam_pose_from_global_matrix(const float* t_wc16, double* pose6)
+{
+    soslam_host::Mat4f m;
+    std::memcpy(m.m, t_wc16, sizeof m.m);
+    std::array<double, 6> p;
+    soslam_host::MatrixToPose(m.inverse(), p);
+    std::memcpy(pose6, p.data(), sizeof(double) * 6);
+}
+
+void soslam_global_matrix_from_pose(const double* pose6, float* t_wc16)
+{
+    std::array<double, 6> p;
+    std::memcpy(p.data(), pose6, sizeof(double) * 6);
+    soslam_host::Mat4f m;
+    soslam_host::PoseToMatrix(p, m);
+    const soslam_host::Mat4f inv = m.inverse();
+    std::memcpy(t_wc16, inv.m, sizeof inv.m);
+}
+
+}  // extern "C"

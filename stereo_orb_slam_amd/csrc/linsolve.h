@@ -1,0 +1,44 @@
+// linsolve.h - reduced camera system solvers on the device (definitions in linsolve.hip).
+//
+// The reference solves this system with SPARSE_SCHUR + CHOLMOD (/root/reference/src/bundle_adjuster.cpp:26-29),
+// a direct factorisation.  Two device paths replace it:
+//   dense Cholesky  - block-sparse S expanded to a dense lower triangle, blocked right-looking
+//                     factorisation (BASELINE.json configs[1]: "full Schur complement + dense camera solve");
+//   PCG             - block-Jacobi preconditioned conjugate gradients on the block-sparse S
+//                     (configs[2]: "PCG on Schur-complemented system").
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace soslam {
+
+// Symmetric block-sparse matrix, 6x6 row-major blocks stored once for the upper triangle (i <= j).
+// Row lists hold BOTH triangles: entry e of block-row i refers to block ent_blk[e] in column ent_col[e],
+// used transposed when ent_trans[e] != 0.
+struct BsrView {
+    uint32_t n_rows;             // block rows (free cameras)
+    const uint32_t* row_ptr;     // [n_rows + 1]
+    const uint32_t* ent_col;     // [n_ent]
+    const uint32_t* ent_blk;     // [n_ent]
+    const uint8_t* ent_trans;    // [n_ent]
+    const int32_t* diag_block;   // [n_rows]
+    const double* blocks;        // [n_blocks][36]
+};
+
+// x = S^-1 b by block-Jacobi PCG; resid receives the final recurrence residual b - S x.
+// work: 4 * 6 * n_rows f64 (p, z, q, spare) + 36 * n_rows (preconditioner).
+// scal[SC_LIN_ITERS], scal[SC_LIN_RESID] (relative), scal[SC_LIN_STATUS] are written.
+void launch_pcg(hipStream_t s, const BsrView& A, const double* b, double* x, double* resid, double* work,
+                double tol, int max_iter, double* scal);
+
+// Dense path: expand, factor (lower Cholesky, in place), solve.  dense is (6 n_rows)^2 f64.
+// scal[SC_LIN_STATUS] = 1 on a non-positive pivot.
+void launch_bsr_to_dense(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row,
+                         const uint32_t* blk_col, double* dense);
+void launch_dense_cholesky_solve(hipStream_t s, uint32_t n, double* dense, const double* b, double* x, double* scal);
+
+size_t pcg_work_count(uint32_t n_rows);
+
+}  // namespace soslam

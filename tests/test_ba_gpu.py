@@ -1,0 +1,382 @@
+"""GPU parity tests of the BA hot path: HIP kernels (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Bars (BASELINE.json north_star): final cost within 1e-5 relative, pose parameters
+within 1e-4; per-observation blocks within f64 rounding (abs 1e-10 / rel 1e-12 scaled)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_COST = 1e-5     # north_star: 1e-5 relative on the final residual
+ABS_POSE = 1e-4     # north_star: 1e-4 on pose parameters
+
+
+@pytest.fixture(scope="module")
+def gpu(soslam):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no fallback")
+    from stereo_orb_slam_amd import ba, synth
+    return ba, synth, soslam
+
+
+@pytest.fixture(scope="module")
+def prob1(gpu):
+    return gpu[1].generate_ba(1)
+
+
+@pytest.fixture(scope="module")
+def prob2(gpu):
+    return gpu[1].generate_ba(2)
+
+
+def _oracle_solve(oracle_lib, prob, **kw):
+    o = oracle_lib.default_options(**kw)
+    return oracle_lib.solve(prob.obs_cam, prob.obs_pt, prob.obs_uv, prob.poses_cw(), prob.points_f64(), prob.proj_l,
+                            prob.proj_r, prob.cam_fixed, o)
+
+
+def test_residual_jacobian_golden(gpu, golden_dir):
+    """ba_linearize against torch-autograd golden blocks, incl. zero / tiny / near-pi rotations and general 3x4
+    projections.  Each case is its own 1-camera 1-point problem (the projection is per handle)."""
+    ba, synth, L = gpu
+    g = np.load(os.path.join(golden_dir, "ba_residual_jacobian.npz"))
+    # group cases by projection so one handle serves many
+    keys = {}
+    for i in range(len(g["cam"])):
+        keys.setdefault((g["proj_l"][i].tobytes(), g["proj_r"][i].tobytes()), []).append(i)
+    worst = 0.0
+    for idx in keys.values():
+        n = len(idx)
+        with ba.BundleAdjustment(ba.default_options(huber_delta=1e300)) as h:  # huge delta: no loss correction
+            h.set_projection(g["proj_l"][idx[0]], g["proj_r"][idx[0]])
+            h.set_problem(n, n, np.arange(n, dtype=np.uint32), np.arange(n, dtype=np.uint32),
+                          g["uv"][idx].astype(np.float32), np.zeros(n, np.uint8))
+            h.set_state(g["cam"][idx], g["pt"][idx])
+            h.debug_step(1e4)
+            r, jc, jp = h.debug_read(L.DBG_RESIDUALS), h.debug_read(L.DBG_JAC_CAM), h.debug_read(L.DBG_JAC_POINT)
+        for k, i in enumerate(idx):
+            uv32 = g["uv"][i].astype(np.float32).astype(np.float64)   # observations are stored float32
+            np.testing.assert_allclose(r[k], g["r"][i] + (g["uv"][i] - uv32), rtol=1e-12, atol=1e-9)
+            th = np.linalg.norm(g["cam"][i][:3])
+            scale = max(1.0, np.abs(g["jc"][i]).max())
+            # the golden's own Rodrigues (1 - cos) cancellation costs ~eps/theta at tiny angles
+            slack = 0.0 if (th == 0 or th > 1e-3) else 1e-16 / th * 1e4
+            np.testing.assert_allclose(jc[k], g["jc"][i], rtol=1e-9, atol=(1e-10 + slack) * scale)
+            np.testing.assert_allclose(jp[k], g["jp"][i], rtol=1e-9, atol=(1e-10 + slack) * scale)
+            worst = max(worst, np.abs(jc[k] - g["jc"][i]).max() / scale)
+    assert worst < 1e-6
+
+
+def test_linearize_matches_oracle(gpu, oracle_lib, prob1):
+    ba, synth, L = gpu
+    cams, pts = prob1.poses_cw(), prob1.points_f64()
+    cost, r, jc, jp = oracle_lib.linearize(prob1.obs_cam, prob1.obs_pt, prob1.obs_uv, cams, pts, prob1.proj_l, prob1.proj_r,
+                                           prob1.cam_fixed)
+    with ba.BundleAdjustment() as h:
+        h.load(prob1)
+        h.debug_step(1e4)
+        gr, gjc, gjp = h.debug_read(L.DBG_RESIDUALS), h.debug_read(L.DBG_JAC_CAM), h.debug_read(L.DBG_JAC_POINT)
+        gcost = h.debug_read(L.DBG_COST)[0]
+    assert gcost == pytest.approx(cost, rel=1e-12)
+    np.testing.assert_allclose(gr, r, rtol=1e-10, atol=1e-9)
+    sc = np.abs(jc).max()
+    np.testing.assert_allclose(gjc, jc, rtol=1e-9, atol=1e-12 * sc)
+    np.testing.assert_allclose(gjp, jp, rtol=1e-9, atol=1e-12 * sc)
+    # gauge: the fixed camera's pose block is zero, and both Huber branches are exercised
+    assert not gjc[prob1.obs_cam == 0].any()
+    s = (gr * gr).sum(1)
+    assert (s > 1.0).any() and (s < 1.0).any()
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_one_step_matches_oracle(gpu, oracle_lib, prob1, solver):
+    """Reduced camera system, camera step, point step and step scalars of one trust-region step."""
+    ba, synth, L = gpu
+    ref = oracle_lib.step(prob1.obs_cam, prob1.obs_pt, prob1.obs_uv, prob1.poses_cw(), prob1.points_f64(), prob1.proj_l,
+                          prob1.proj_r, prob1.cam_fixed, 1e4)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=solver, pcg_tolerance=1e-14)) as h:
+        h.load(prob1)
+        h.debug_step(1e4)
+        S, rhs = h.debug_read(L.DBG_S_DENSE), h.debug_read(L.DBG_RHS)
+        dc, dp, sc = h.debug_read(L.DBG_STEP_CAM), h.debug_read(L.DBG_STEP_POINT), h.debug_read(L.DBG_STEP_SCALARS)
+    np.testing.assert_allclose(S, ref["S"], rtol=1e-9, atol=1e-11 * np.abs(ref["S"]).max())
+    np.testing.assert_allclose(rhs, ref["rhs"], rtol=1e-9, atol=1e-11 * np.abs(ref["rhs"]).max())
+    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-6, atol=1e-9 * np.abs(ref["dc"]).max())
+    np.testing.assert_allclose(dp, ref["dp"], rtol=1e-6, atol=1e-9 * np.abs(ref["dp"]).max())
+    assert sc[0] == pytest.approx(ref["cost"], rel=1e-12)
+    assert sc[1] == pytest.approx(ref["model_cost_change"], rel=1e-7)   # algebraic identity vs explicit J*delta
+    assert sc[2] == pytest.approx(ref["candidate_cost"], rel=1e-9)
+    assert sc[3] == pytest.approx(ref["step_norm"], rel=1e-7)
+
+
+def test_one_step_matches_dense_golden(gpu, golden_dir):
+    """The same step against numpy.linalg.solve on the full (un-eliminated) normal equations."""
+    ba, synth, L = gpu
+    g = np.load(os.path.join(golden_dir, "ba_step_dense.npz"))
+    n_cam, n_pt = len(g["cams"]), len(g["pts"])
+    fixed = np.zeros(n_cam, np.uint8)
+    fixed[0] = 1
+    with ba.BundleAdjustment(ba.default_options(linear_solver=1)) as h:
+        h.set_projection(g["proj_l"], g["proj_r"])
+        h.set_problem(n_cam, n_pt, g["obs_cam"], g["obs_pt"], g["obs_uv"], fixed)
+        h.set_state(g["cams"], g["pts"])
+        h.debug_step(float(g["radius"]))
+        S, rhs = h.debug_read(L.DBG_S_DENSE), h.debug_read(L.DBG_RHS)
+        dc, dp, sc = h.debug_read(L.DBG_STEP_CAM), h.debug_read(L.DBG_STEP_POINT), h.debug_read(L.DBG_STEP_SCALARS)
+    np.testing.assert_allclose(S, g["S"], rtol=1e-7, atol=1e-6 * np.abs(g["S"]).max())
+    np.testing.assert_allclose(rhs, g["rhs"], rtol=1e-7, atol=1e-7 * np.abs(g["rhs"]).max())
+    np.testing.assert_allclose(dc, g["dc"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(dp, g["dp"], rtol=1e-6, atol=1e-8)
+    assert sc[1] == pytest.approx(float(g["model_cost_change"]), rel=1e-8)
+    assert sc[2] == pytest.approx(float(g["candidate_cost"]), rel=1e-8)
+
+
+def _compare_solutions(summ, cams, pts, osum, ocams, opts_):
+    assert summ.final_cost == pytest.approx(osum.final_cost, rel=REL_COST)
+    assert np.abs(cams - ocams).max() < ABS_POSE
+    assert np.abs(pts - opts_).max() < 1e-3 * max(1.0, np.abs(opts_).max())
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_full_solve_config1_matches_oracle(gpu, oracle_lib, prob1, solver):
+    """BASELINE.json configs[0] stand-in: 10 keyframes / 2k points / ~8k observations, 50 iterations."""
+    ba, synth, L = gpu
+    ocams, opts_, osum, olog = _oracle_solve(oracle_lib, prob1)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=solver)) as h:
+        h.load(prob1)
+        summ = h.solve()
+        cams, pts = h.get_state()
+        log = h.iteration_log()
+    assert summ.initial_cost == pytest.approx(osum.initial_cost, rel=1e-12)
+    _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+    np.testing.assert_array_equal(cams[0], prob1.poses_cw()[0])           # first pose constant
+    # same accept/reject sequence and termination as the oracle's controller
+    assert summ.iterations == osum.iterations and summ.termination == osum.termination
+    assert [e.accepted for e in log] == [e.accepted for e in olog]
+    assert summ.armijo_violations == osum.armijo_violations
+
+
+def test_solve_reaches_scipy_minimum(gpu, golden_dir):
+    ba, synth, L = gpu
+    g = np.load(os.path.join(golden_dir, "ba_minimum_scipy.npz"))
+    n_cam, n_pt = len(g["cams0"]), len(g["pts0"])
+    fixed = np.zeros(n_cam, np.uint8)
+    fixed[0] = 1
+    with ba.BundleAdjustment(ba.default_options(max_iterations=200)) as h:
+        h.set_projection(g["proj_l"], g["proj_r"])
+        h.set_problem(n_cam, n_pt, g["obs_cam"], g["obs_pt"], g["obs_uv"], fixed)
+        h.set_state(g["cams0"], g["pts0"])
+        summ = h.solve()
+        cams, pts = h.get_state()
+    assert summ.termination in (1, 2)
+    assert summ.final_cost == pytest.approx(float(g["cost"]), rel=REL_COST)
+    assert np.abs(cams - g["cams"]).max() < ABS_POSE
+
+
+def test_config2_dense_and_pcg_match_oracle(gpu, oracle_lib, prob2):
+    """BASELINE.json configs[1]: 100 poses / 20k points / 200k observations, full Schur + dense camera solve;
+    the PCG path must land on the same iterates."""
+    ba, synth, L = gpu
+    iters = 15
+    ocams, opts_, osum, olog = _oracle_solve(oracle_lib, prob2, max_iterations=iters, num_threads=4)
+    for solver in (1, 2):
+        with ba.BundleAdjustment(ba.default_options(linear_solver=solver, max_iterations=iters)) as h:
+            h.load(prob2)
+            summ = h.solve()
+            cams, pts = h.get_state()
+            log = h.iteration_log()
+        assert summ.linear_solver == solver
+        _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+        assert [e.accepted for e in log] == [e.accepted for e in olog]
+        costs = [e.cost for e in log]
+        assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+
+
+def test_structure_only_single_fixed_camera(gpu, oracle_lib, prob1):
+    """BundleAdjuster::Optimize(n-1, n) (/root/reference/src/slam.cpp:123): one constant pose, points only."""
+    ba, synth, L = gpu
+    keep = prob1.obs_cam == 3
+    pts_ids = np.unique(prob1.obs_pt[keep])
+    remap = -np.ones(prob1.n_pt, np.int64)
+    remap[pts_ids] = np.arange(len(pts_ids))
+    oc = np.zeros(int(keep.sum()), np.uint32)
+    op = remap[prob1.obs_pt[keep]].astype(np.uint32)
+    uv = prob1.obs_uv[keep]
+    cam = prob1.poses_cw()[3:4]
+    pts0 = prob1.points_f64()[pts_ids]
+    fixed = np.ones(1, np.uint8)
+    o = oracle_lib.default_options()
+    ocams, opts_, osum, _ = oracle_lib.solve(oc, op, uv, cam, pts0, prob1.proj_l, prob1.proj_r, fixed, o)
+    with ba.BundleAdjustment() as h:
+        h.set_projection(prob1.proj_l, prob1.proj_r)
+        h.set_problem(1, len(pts0), oc, op, uv, fixed)
+        h.set_state(cam, pts0)
+        summ = h.solve()
+        cams, pts = h.get_state()
+    np.testing.assert_array_equal(cams, cam)
+    assert summ.final_cost == pytest.approx(osum.final_cost, rel=REL_COST, abs=1e-12)
+    np.testing.assert_allclose(pts, opts_, rtol=1e-6, atol=1e-6)
+
+
+def test_observation_order_invariance(gpu, prob1):
+    """The solver sorts observations itself (camera-major, point-major): a shuffled input gives the same
+    reduced system to rounding and the same solution."""
+    ba, synth, L = gpu
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(prob1.n_obs)
+    out = []
+    for order in (np.arange(prob1.n_obs), perm):
+        with ba.BundleAdjustment(ba.default_options(linear_solver=1, max_iterations=8)) as h:
+            h.set_projection(prob1.proj_l, prob1.proj_r)
+            h.set_problem(prob1.n_cam, prob1.n_pt, prob1.obs_cam[order], prob1.obs_pt[order], prob1.obs_uv[order], prob1.cam_fixed)
+            h.set_state(prob1.poses_cw(), prob1.points_f64())
+            summ = h.solve()
+            out.append((summ.final_cost, *h.get_state()))
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-9)
+    np.testing.assert_allclose(out[0][1], out[1][1], atol=1e-8)
+
+
+def test_zero_residual_is_a_fixed_point(gpu):
+    """Noise-free observations of the true geometry: cost 0, nothing moves."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, with_truth=True, n_cam=6, n_pt=300, track_mode=0, track_len=4, spacing=0.7,
+                          pixel_sigma=0.0, outlier_frac=0.0, pose_rot_sigma=0.0, pose_trans_sigma=0.0, depth_noise=0.0)
+    with ba.BundleAdjustment(ba.default_options(max_iterations=5)) as h:
+        h.load(p)
+        summ = h.solve()
+        cams, pts = h.get_state()
+    # observations and the initial state are rounded to float32, so "zero" is float32 pixel rounding
+    assert summ.initial_cost < 1e-2 * p.n_obs * 1e-3
+    assert summ.final_cost <= summ.initial_cost
+    assert np.abs(cams - p.poses_cw()).max() < 1e-3
+
+
+def test_virtual_ranks_sum_to_the_unsharded_system(gpu, prob1):
+    """Multi-GPU decomposition on ONE device: every 'rank' builds its shard's reduced system; the all-reduce
+    callback adds the other shards' payloads (captured in a first pass).  Each rank must then hold exactly
+    the unsharded system and camera step."""
+    import torch
+    ba, synth, L = gpu
+    world = 3
+    with ba.BundleAdjustment(ba.default_options(linear_solver=1)) as h:
+        h.load(prob1)
+        h.debug_step(1e4)
+        S_ref, rhs_ref, dc_ref = h.debug_read(L.DBG_S_DENSE), h.debug_read(L.DBG_RHS), h.debug_read(L.DBG_STEP_CAM)
+        sc_ref = h.debug_read(L.DBG_STEP_SCALARS)
+    pairs = prob1.covisibility_pairs()
+    handles = []
+    for r in range(world):
+        h = ba.BundleAdjustment(ba.default_options(linear_solver=1))
+        h.set_covisibility(pairs)
+        h.load(prob1.shard(r, world))
+        n = h.reduce_buffer_count()
+        t = torch.zeros(n, dtype=torch.float64, device="cuda")
+        h.set_reduce_buffer(t.data_ptr(), n)
+        handles.append((h, t))
+    assert len({t.numel() for _, t in handles}) == 1, "all ranks must agree on the payload layout"
+    captured = [dict() for _ in range(world)]
+
+    def make_cb(r, t, reduce):
+        base = t.data_ptr()
+        seen = []
+        def cb(ptr, count, op, stream):
+            torch.cuda.synchronize()
+            off = (ptr - base) // 8
+            call = len(seen)
+            seen.append((off, count))
+            if not reduce:
+                captured[r][call] = t[off:off + count].clone()
+            elif call == 0:   # the system payload; later payloads depend on the reduced solve
+                for q in range(world):
+                    if q != r:
+                        t[off:off + count] += captured[q][0]
+            torch.cuda.synchronize()
+            return 0
+        return cb
+
+    for r, (h, t) in enumerate(handles):
+        h.set_allreduce(make_cb(r, t, False), r, world)
+        h.debug_step(1e4)
+    total_cost = 0.0
+    for r, (h, t) in enumerate(handles):
+        h.set_allreduce(make_cb(r, t, True), r, world)
+        h.debug_step(1e4)
+        S, rhs, dc = h.debug_read(L.DBG_S_DENSE), h.debug_read(L.DBG_RHS), h.debug_read(L.DBG_STEP_CAM)
+        np.testing.assert_allclose(S, S_ref, rtol=1e-10, atol=1e-11 * np.abs(S_ref).max())
+        np.testing.assert_allclose(rhs, rhs_ref, rtol=1e-10, atol=1e-11 * np.abs(rhs_ref).max())
+        np.testing.assert_allclose(dc, dc_ref, rtol=1e-7, atol=1e-10)   # every rank solves the same system
+        assert h.debug_read(L.DBG_STEP_SCALARS)[0] == pytest.approx(sc_ref[0], rel=1e-12)  # summed cost
+    for h, _ in handles:
+        h.close()
+
+
+def test_errors_leave_caller_arrays_untouched(gpu, prob1):
+    ba, synth, L = gpu
+    bad_cam = prob1.obs_cam.copy()
+    bad_cam[5] = prob1.n_cam + 3
+    with ba.BundleAdjustment() as h:
+        h.set_projection(prob1.proj_l, prob1.proj_r)
+        with pytest.raises(L.SoslamError) as e:
+            h.set_problem(prob1.n_cam, prob1.n_pt, bad_cam, prob1.obs_pt, prob1.obs_uv, prob1.cam_fixed)
+        assert e.value.status == L.ERR_INVALID_ARGUMENT
+        with pytest.raises(L.SoslamError) as e:
+            h.solve()
+        assert e.value.status == L.ERR_STATE
+    # soslam_ba_optimize: arrays unchanged on failure
+    import ctypes as C
+    c, p = prob1.poses_cw(), prob1.points_f64()
+    c0, p0 = c.copy(), p.copy()
+    s = L.BaSummary()
+    o = ba.default_options()
+    fx = np.ascontiguousarray(prob1.cam_fixed)
+    st = L.lib().soslam_ba_optimize(C.byref(o), L.ptr(np.ascontiguousarray(prob1.proj_l)), L.ptr(np.ascontiguousarray(prob1.proj_r)),
+                                    prob1.n_cam, L.ptr(c), prob1.n_pt, L.ptr(p), prob1.n_obs, L.ptr(bad_cam),
+                                    L.ptr(np.ascontiguousarray(prob1.obs_pt)), L.ptr(np.ascontiguousarray(prob1.obs_uv)),
+                                    L.ptr(fx), C.byref(s))
+    assert st == L.ERR_INVALID_ARGUMENT
+    np.testing.assert_array_equal(c, c0)
+    np.testing.assert_array_equal(p, p0)
+
+
+def test_optimize_one_call(gpu, oracle_lib, prob1):
+    ba, synth, L = gpu
+    cams, pts, summ = ba.optimize(prob1, ba.default_options(max_iterations=10))
+    ocams, opts_, osum, _ = _oracle_solve(oracle_lib, prob1, max_iterations=10)
+    _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+
+
+def test_long_tracks_use_the_wide_window(gpu, oracle_lib):
+    """Tracks of 24 cameras select the 32-slot Schur window."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, n_cam=40, n_pt=1500, track_mode=0, track_len=24, spacing=0.3)
+    ref = oracle_lib.step(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, 1e4)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=1)) as h:
+        h.load(p)
+        h.debug_step(1e4)
+        S, dc = h.debug_read(L.DBG_S_DENSE), h.debug_read(L.DBG_STEP_CAM)
+    np.testing.assert_allclose(S, ref["S"], rtol=1e-9, atol=1e-11 * np.abs(ref["S"]).max())
+    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-5, atol=1e-8 * np.abs(ref["dc"]).max())
+
+
+def test_full_size_properties_config3(gpu):
+    """BASELINE.json configs[2] at full size (500 / 100k / 1M): size-independent properties - monotone cost,
+    PCG and dense Cholesky agree on the first steps, the first pose never moves, bounds respected."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(3)
+    res = {}
+    for solver in (2, 1):
+        with ba.BundleAdjustment(ba.default_options(linear_solver=solver, max_iterations=6)) as h:
+            h.load(p)
+            summ = h.solve()
+            cams, pts = h.get_state()
+            log = h.iteration_log()
+        costs = [e.cost for e in log]
+        assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))
+        assert summ.final_cost < 0.25 * summ.initial_cost
+        np.testing.assert_array_equal(cams[0], p.poses_cw()[0])
+        assert np.abs(pts).max() <= 1e4
+        res[solver] = (summ.final_cost, cams)
+    assert res[1][0] == pytest.approx(res[2][0], rel=REL_COST)
+    assert np.abs(res[1][1] - res[2][1]).max() < ABS_POSE
