@@ -40,7 +40,15 @@ enum {
     SOSLAM_ERR_STATE = 7             /* call sequence error (no problem / no state set) */
 };
 
-enum { SOSLAM_SOLVER_AUTO = 0, SOSLAM_SOLVER_DENSE_CHOLESKY = 1, SOSLAM_SOLVER_PCG = 2 };
+/*
+ * Reduced camera system solvers (the reference: SPARSE_SCHUR + CHOLMOD, /root/reference/src/bundle_adjuster.cpp:26-29).
+ *   DENSE_CHOLESKY  block-sparse S expanded to dense, blocked right-looking Cholesky
+ *   PCG             conjugate gradients on the block-sparse S; preconditioner = block-band Cholesky factor when
+ *                   S fits a band of <= 15 block diagonals (camera chains), block-Jacobi otherwise
+ *   BAND_CHOLESKY   direct block-band Cholesky (requires the <= 15 block-diagonal band)
+ *   AUTO            BAND_CHOLESKY if the band fits, else DENSE_CHOLESKY up to 1200 camera dof, else PCG
+ */
+enum { SOSLAM_SOLVER_AUTO = 0, SOSLAM_SOLVER_DENSE_CHOLESKY = 1, SOSLAM_SOLVER_PCG = 2, SOSLAM_SOLVER_BAND_CHOLESKY = 3 };
 
 enum {
     SOSLAM_TERM_MAX_ITERATIONS = 0,
@@ -62,7 +70,7 @@ enum {
 typedef struct soslam_ba_options {
     int32_t max_iterations;          /* 50 */
     int32_t check_termination;       /* 1; 0 = run exactly max_iterations LM iterations */
-    int32_t linear_solver;           /* SOSLAM_SOLVER_*; AUTO = dense Cholesky up to 1200 camera dof, PCG above */
+    int32_t linear_solver;           /* SOSLAM_SOLVER_* */
     int32_t pcg_max_iterations;      /* 500 */
     double  pcg_tolerance;           /* relative residual |r|/|b| at which the reduced solve stops, 1e-10 */
     double  huber_delta;             /* 1.0 */

@@ -20,7 +20,7 @@ NUM_STAGES = 8
 STAGE_NAMES = ["linearize", "point_reduce", "schur", "allreduce", "solve", "backsub", "cost", "sync"]
 
 (OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_NON_FINITE, ERR_LINEAR_SOLVER, ERR_COMM, ERR_STATE) = range(8)
-SOLVER_AUTO, SOLVER_DENSE_CHOLESKY, SOLVER_PCG = 0, 1, 2
+SOLVER_AUTO, SOLVER_DENSE_CHOLESKY, SOLVER_PCG, SOLVER_BAND_CHOLESKY = 0, 1, 2, 3
 TERM_NAMES = ["max_iterations", "parameter_tolerance", "function_tolerance", "gradient_tolerance", "min_radius",
               "invalid_steps", "time"]
 KERNEL_LINEARIZE, KERNEL_COST, KERNEL_POINT_REDUCE, KERNEL_SCHUR, KERNEL_BACKSUB = range(5)

@@ -59,6 +59,8 @@ struct soslam_ba {
     uint32_t n_cam = 0, n_pt = 0, n_obs = 0, n_free = 0, n_tiles = 0, n_chunks = 0, n_batches = 0, n_blocks = 0;
     uint32_t n_point_blocks = 0;
     int kmax = 16;
+    int bw = 0;                         // block half-bandwidth of the reduced camera matrix
+    bool pcg_band = false;              // PCG preconditioned by the band factor
     int solver = SOSLAM_SOLVER_PCG;
     double setup_seconds = 0.0;
 
@@ -82,7 +84,7 @@ struct soslam_ba {
     DevBuf<double> cams[2], pts[2];
     int cur = 0;
     DevBuf<double> jc, jpr, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
-    DevBuf<double> lin_resid, lin_work, dense;
+    DevBuf<double> lin_resid, lin_work, dense, band, band_dinv;
     DevBuf<double> reduce_own;          // library-owned reduce buffer
     double* reduce = nullptr;           // [S blocks | rhs | diagB | gc_red | tail(4)] [scalars(SC_COUNT)]
     uint64_t reduce_main = 0;           // f64 in the per-iteration system payload
@@ -394,8 +396,18 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     h->n_point_blocks = div_up(n_pt, kPointBlock);
 
     // solver choice
+    h->bw = 0;
+    for (uint32_t b = 0; b < h->n_blocks; b++) h->bw = std::max<int>(h->bw, (int)(h->h_blk_col[b] - h->h_blk_row[b]));
+    const bool band_fits = h->bw <= kBandMax;
     h->solver = h->opt.linear_solver;
-    if (h->solver == SOSLAM_SOLVER_AUTO) h->solver = (nf * 6 <= (uint32_t)kDenseAutoLimit) ? SOSLAM_SOLVER_DENSE_CHOLESKY : SOSLAM_SOLVER_PCG;
+    if (h->solver == SOSLAM_SOLVER_AUTO)
+        h->solver = band_fits ? SOSLAM_SOLVER_BAND_CHOLESKY
+                              : ((nf * 6 <= (uint32_t)kDenseAutoLimit) ? SOSLAM_SOLVER_DENSE_CHOLESKY : SOSLAM_SOLVER_PCG);
+    if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY && !band_fits) {
+        set_last_error("band Cholesky requested but the reduced matrix spans %d block diagonals (limit %d)", h->bw, kBandMax);
+        return SOSLAM_ERR_INVALID_ARGUMENT;
+    }
+    h->pcg_band = h->solver == SOSLAM_SOLVER_PCG && band_fits;
 
     // uploads
     SOSLAM_CHECK(h->uv.upload(uv, s));
@@ -450,6 +462,13 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         SOSLAM_CHECK(h->dense.alloc(n6 * n6 + (size_t)div_up(n6, 32) * 32 * 32 + 1024));
     } else {
         h->dense.release();
+    }
+    if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) {
+        SOSLAM_CHECK(h->band.alloc(band_count(nf, h->bw)));
+        SOSLAM_CHECK(h->band_dinv.alloc((size_t)nf * 36));
+    } else {
+        h->band.release();
+        h->band_dinv.release();
     }
     h->reduce_main = (uint64_t)h->n_blocks * 36 + (uint64_t)nf * 18 + 4;
     h->reduce_count = h->reduce_main + SC_COUNT;
@@ -530,6 +549,16 @@ int take_step(soslam_ba* h, double radius)
             if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
                 launch_bsr_to_dense(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->dense.p);
                 launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
+            } else if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
+                launch_bsr_to_band(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->band.p);
+                launch_band_cholesky(s, h->n_free, h->bw, h->band.p, h->band_dinv.p, h->scalp());
+                launch_band_solve(s, h->n_free, h->bw, h->band.p, h->band_dinv.p, h->rhs(), h->dc_free.p);
+            } else if (h->pcg_band) {
+                launch_bsr_to_band(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->band.p);
+                launch_band_cholesky(s, h->n_free, h->bw, h->band.p, h->band_dinv.p, h->scalp());
+                launch_pcg_band(s, bsr_view(h), h->bw, h->band.p, h->band_dinv.p, h->rhs(), h->dc_free.p, h->lin_resid.p,
+                                h->lin_work.p, h->opt.pcg_tolerance, h->opt.pcg_max_iterations, h->scalp());
+                resid = h->lin_resid.p;
             } else {
                 launch_pcg(s, bsr_view(h), h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance,
                            h->opt.pcg_max_iterations, h->scalp());

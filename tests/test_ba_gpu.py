@@ -90,7 +90,7 @@ def test_linearize_matches_oracle(gpu, oracle_lib, prob1):
     assert (s > 1.0).any() and (s < 1.0).any()
 
 
-@pytest.mark.parametrize("solver", [1, 2])
+@pytest.mark.parametrize("solver", [1, 2, 3])
 def test_one_step_matches_oracle(gpu, oracle_lib, prob1, solver):
     """Reduced camera system, camera step, point step and step scalars of one trust-region step."""
     ba, synth, L = gpu
@@ -139,7 +139,7 @@ def _compare_solutions(summ, cams, pts, osum, ocams, opts_):
     assert np.abs(pts - opts_).max() < 1e-3 * max(1.0, np.abs(opts_).max())
 
 
-@pytest.mark.parametrize("solver", [1, 2])
+@pytest.mark.parametrize("solver", [1, 2, 3])
 def test_full_solve_config1_matches_oracle(gpu, oracle_lib, prob1, solver):
     """BASELINE.json configs[0] stand-in: 10 keyframes / 2k points / ~8k observations, 50 iterations."""
     ba, synth, L = gpu
@@ -181,7 +181,7 @@ def test_config2_dense_and_pcg_match_oracle(gpu, oracle_lib, prob2):
     ba, synth, L = gpu
     iters = 15
     ocams, opts_, osum, olog = _oracle_solve(oracle_lib, prob2, max_iterations=iters, num_threads=4)
-    for solver in (1, 2):
+    for solver in (1, 2, 3):
         with ba.BundleAdjustment(ba.default_options(linear_solver=solver, max_iterations=iters)) as h:
             h.load(prob2)
             summ = h.solve()
@@ -347,6 +347,32 @@ def test_optimize_one_call(gpu, oracle_lib, prob1):
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
 
 
+def test_block_jacobi_pcg_when_the_band_does_not_fit(gpu, oracle_lib, prob1):
+    """A loop-closure-like problem: an extra point seen by the first and last cameras of a longer chain puts a
+    block far off the diagonal, so the band factor is unavailable and PCG falls back to block-Jacobi."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, n_cam=30, n_pt=900, track_mode=0, track_len=5, spacing=0.5)
+    # tie camera 1 and camera 29 together through 20 far points observed by both
+    rng = np.random.default_rng(5)
+    extra_pts = p.points[:20].copy() + np.array([0, 0, 40.0], np.float32)
+    ids = np.arange(p.n_pt, p.n_pt + 20, dtype=np.uint32)
+    oc = np.concatenate([p.obs_cam, np.full(20, 1, np.uint32), np.full(20, 29, np.uint32)])
+    op = np.concatenate([p.obs_pt, ids, ids])
+    uv = np.concatenate([p.obs_uv, rng.uniform(100, 1000, (40, 4)).astype(np.float32)])
+    order = np.lexsort((op, oc))
+    q = synth.BaProblem(p.poses_wc, np.concatenate([p.points, extra_pts]), oc[order], op[order], uv[order], p.proj_l, p.proj_r)
+    ref = oracle_lib.step(q.obs_cam, q.obs_pt, q.obs_uv, q.poses_cw(), q.points_f64(), q.proj_l, q.proj_r, q.cam_fixed, 1e2)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=2, pcg_tolerance=1e-13, pcg_max_iterations=3000)) as h:
+        h.load(q)
+        h.debug_step(1e2)
+        S, dc = h.debug_read(L.DBG_S_DENSE), h.debug_read(L.DBG_STEP_CAM)
+    np.testing.assert_allclose(S, ref["S"], rtol=1e-9, atol=1e-11 * np.abs(ref["S"]).max())
+    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-4, atol=1e-6 * np.abs(ref["dc"]).max())
+    with pytest.raises(L.SoslamError):
+        with ba.BundleAdjustment(ba.default_options(linear_solver=3)) as h:
+            h.load(q)
+
+
 def test_long_tracks_use_the_wide_window(gpu, oracle_lib):
     """Tracks of 24 cameras select the 32-slot Schur window."""
     ba, synth, L = gpu
@@ -366,7 +392,7 @@ def test_full_size_properties_config3(gpu):
     ba, synth, L = gpu
     p = synth.generate_ba(3)
     res = {}
-    for solver in (2, 1):
+    for solver in (2, 3, 1):
         with ba.BundleAdjustment(ba.default_options(linear_solver=solver, max_iterations=6)) as h:
             h.load(p)
             summ = h.solve()
@@ -378,5 +404,6 @@ def test_full_size_properties_config3(gpu):
         np.testing.assert_array_equal(cams[0], p.poses_cw()[0])
         assert np.abs(pts).max() <= 1e4
         res[solver] = (summ.final_cost, cams)
-    assert res[1][0] == pytest.approx(res[2][0], rel=REL_COST)
-    assert np.abs(res[1][1] - res[2][1]).max() < ABS_POSE
+    for solver in (2, 3):   # PCG (band-preconditioned) and direct band Cholesky against the dense factorisation
+        assert res[1][0] == pytest.approx(res[solver][0], rel=REL_COST)
+        assert np.abs(res[1][1] - res[solver][1]).max() < ABS_POSE
