@@ -84,7 +84,7 @@ struct soslam_ba {
     DevBuf<double> cams[2], pts[2];
     int cur = 0;
     DevBuf<double> jc, jpr, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
-    DevBuf<double> lin_resid, lin_work, dense, band, band_dinv;
+    DevBuf<double> lin_resid, lin_work, dense, band, bandT, band_dinv;
     DevBuf<double> reduce_own;          // library-owned reduce buffer
     double* reduce = nullptr;           // [S blocks | rhs | diagB | gc_red | tail(4)] [scalars(SC_COUNT)]
     uint64_t reduce_main = 0;           // f64 in the per-iteration system payload
@@ -454,7 +454,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->dp.alloc((size_t)n_pt * 3));
     SOSLAM_CHECK(h->part.alloc((size_t)h->n_point_blocks * 5));
     SOSLAM_CHECK(h->lin_resid.alloc((size_t)nf * 6));
-    SOSLAM_CHECK(h->lin_work.alloc(pcg_work_count(nf)));
+    SOSLAM_CHECK(h->lin_work.alloc(std::max(pcg_work_count(nf), pcg_band_work_count(nf))));
     SOSLAM_CHECK(h->B.zero(s)); SOSLAM_CHECK(h->gc.zero(s)); SOSLAM_CHECK(h->dc_free.zero(s)); SOSLAM_CHECK(h->Cinv.zero(s));
     SOSLAM_CHECK(h->lin_resid.zero(s));
     if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
@@ -465,9 +465,12 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     }
     if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) {
         SOSLAM_CHECK(h->band.alloc(band_count(nf, h->bw)));
+        SOSLAM_CHECK(h->bandT.alloc(band_count(nf, h->bw)));
+        SOSLAM_CHECK(h->bandT.zero(s));
         SOSLAM_CHECK(h->band_dinv.alloc((size_t)nf * 36));
     } else {
         h->band.release();
+        h->bandT.release();
         h->band_dinv.release();
     }
     h->reduce_main = (uint64_t)h->n_blocks * 36 + (uint64_t)nf * 18 + 4;
@@ -551,13 +554,14 @@ int take_step(soslam_ba* h, double radius)
                 launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
             } else if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
                 launch_bsr_to_band(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->band.p);
-                launch_band_cholesky(s, h->n_free, h->bw, h->band.p, h->band_dinv.p, h->scalp());
-                launch_band_solve(s, h->n_free, h->bw, h->band.p, h->band_dinv.p, h->rhs(), h->dc_free.p);
+                launch_band_cholesky(s, h->n_free, h->bw, h->band.p, h->bandT.p, h->band_dinv.p, h->scalp());
+                launch_band_solve(s, h->n_free, h->bw, h->band.p, h->bandT.p, h->band_dinv.p, h->rhs(), h->dc_free.p);
             } else if (h->pcg_band) {
                 launch_bsr_to_band(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->band.p);
-                launch_band_cholesky(s, h->n_free, h->bw, h->band.p, h->band_dinv.p, h->scalp());
-                launch_pcg_band(s, bsr_view(h), h->bw, h->band.p, h->band_dinv.p, h->rhs(), h->dc_free.p, h->lin_resid.p,
-                                h->lin_work.p, h->opt.pcg_tolerance, h->opt.pcg_max_iterations, h->scalp());
+                launch_band_cholesky(s, h->n_free, h->bw, h->band.p, h->bandT.p, h->band_dinv.p, h->scalp());
+                launch_pcg_band(s, bsr_view(h), h->bw, h->band.p, h->bandT.p, h->band_dinv.p, h->rhs(), h->dc_free.p,
+                                h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, 4),
+                                h->scalp());
                 resid = h->lin_resid.p;
             } else {
                 launch_pcg(s, bsr_view(h), h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance,

@@ -52,18 +52,22 @@ namespace soslam {
 // Storage: band[(i*(bw+1) + d)*36 + a*6 + b] = S(6i+a, 6(i-d)+b), d = 0..bw (lower block band).
 constexpr int kBandMax = 15;   // widest block half-bandwidth the LDS window admits (78 KB at 15)
 
-size_t band_count(uint32_t n_rows, int bw);                 // f64 in the band array
+size_t band_count(uint32_t n_rows, int bw);                 // f64 in the band array (and in bandT)
+size_t pcg_band_work_count(uint32_t n_rows);                // f64 of PCG work space
 void launch_bsr_to_band(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row,
                         const uint32_t* blk_col, int bw, double* band);
-// in-place Cholesky of the band; dinv[n_rows][36] receives the inverses of the diagonal factor blocks.
+// in-place Cholesky of the band.  bandT receives the factor column-oriented (bandT[k][d] = L(k+d, k)) for the
+// forward solve, dinv[n_rows][36] the inverses of the diagonal factor blocks.
 // scal[SC_LIN_STATUS] = 1 on a non-positive pivot.
-void launch_band_cholesky(hipStream_t s, uint32_t n_rows, int bw, double* band, double* dinv, double* scal);
-// x = (L L^T)^-1 b with the factor above; one workgroup
-void launch_band_solve(hipStream_t s, uint32_t n_rows, int bw, const double* band, const double* dinv,
+void launch_band_cholesky(hipStream_t s, uint32_t n_rows, int bw, double* band, double* bandT, double* dinv, double* scal);
+// x = (L L^T)^-1 b with the factor above; one wave
+void launch_band_solve(hipStream_t s, uint32_t n_rows, int bw, const double* band, const double* bandT, const double* dinv,
                        const double* b, double* x);
-// PCG on the block-sparse S preconditioned by the band factor (exact when every block lies in the band:
-// then one or two iterations of iterative refinement).  work: 4 * 6 * n_rows f64.
-void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band, const double* dinv,
-                     const double* b, double* x, double* resid, double* work, double tol, int max_iter, double* scal);
+// PCG on the block-sparse S preconditioned by the band factor: up to max_rounds rounds of
+// {preconditioner solve (one wave), S p over many workgroups, update + convergence test}; a round whose
+// predecessor converged returns at once on a device-side flag, so the host never synchronises.  With every
+// block of S inside the band the first round already reaches rounding level.
+void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band, const double* bandT, const double* dinv,
+                     const double* b, double* x, double* resid, double* work, double tol, int max_rounds, double* scal);
 
 }  // namespace soslam

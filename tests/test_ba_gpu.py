@@ -373,6 +373,23 @@ def test_block_jacobi_pcg_when_the_band_does_not_fit(gpu, oracle_lib, prob1):
             h.load(q)
 
 
+@pytest.mark.parametrize("solver", [2, 3])
+@pytest.mark.parametrize("track", [3, 12, 16])
+def test_band_solver_widths(gpu, oracle_lib, solver, track):
+    """Block half-bandwidths 2, 11 and 15 (the widest the LDS window admits) through the band factorisation
+    and both triangular-solve variants (one / two update items per lane)."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, n_cam=45, n_pt=1800, track_mode=0, track_len=track, spacing=0.4)
+    ref = oracle_lib.step(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, 1e4)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=solver, pcg_tolerance=1e-12)) as h:
+        h.load(p)
+        h.debug_step(1e4)
+        dc, dp, sc = h.debug_read(L.DBG_STEP_CAM), h.debug_read(L.DBG_STEP_POINT), h.debug_read(L.DBG_STEP_SCALARS)
+    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-6, atol=1e-9 * np.abs(ref["dc"]).max())
+    np.testing.assert_allclose(dp, ref["dp"], rtol=1e-6, atol=1e-9 * np.abs(ref["dp"]).max())
+    assert sc[1] == pytest.approx(ref["model_cost_change"], rel=1e-7)
+
+
 def test_long_tracks_use_the_wide_window(gpu, oracle_lib):
     """Tracks of 24 cameras select the 32-slot Schur window."""
     ba, synth, L = gpu
