@@ -1,0 +1,95 @@
+// bundle_adjuster.cpp - gather / solve / write-back around the C ABI.
+//
+// Conventions kept from /root/reference/src/bundle_adjuster.cpp:39-133:
+//   - half-open frame range [start, end) (:62);
+//   - a pose enters as the WORLD->CAMERA transform: GlobalPose().inverse() -> MatrixToPose (:66-69);
+//   - points are deduplicated in first-seen order over the window (:79-95), float32 -> double;
+//   - the first pose of the window is constant (:113); bounds +-1e4 on every point coordinate (:104-108);
+//   - results: poses first (PoseToMatrix -> inverse -> Frame::GlobalPose, which moves first-observed
+//     points), then every window point is overwritten with its optimised position (:120-132).
+#include "bundle_adjuster.h"
+
+#include <cstdio>
+#include <unordered_map>
+
+#include "mat4f.h"
+#include "params.h"
+#include "reprojection_error.h"
+
+BundleAdjuster::BundleAdjuster(std::vector<Frame*>& cam_frames, std::vector<MapPoint*>& ldm_points)
+    : m_cam_frames(cam_frames), m_ldm_points(ldm_points)
+{
+    soslam_ba_options_default(&m_options);
+    m_options.max_iterations = (int32_t)BA_MAX_ITERATION;
+    m_options.lower_bound = BA_POINT_COORD_LOWER_BOUND;
+    m_options.upper_bound = BA_POINT_COORD_UPPER_BOUND;
+    m_options.huber_delta = 1.0;
+    m_options.function_tolerance = 1e-16;
+    m_options.gradient_tolerance = 1e-16;
+    m_options.verbose = 1;                      // minimizer_progress_to_stdout = true (:15)
+    m_options.max_solver_time_seconds = 0.0;    // set to BA_MAX_TIME_SEC for the stock wall-clock cap (:18)
+}
+
+void BundleAdjuster::Optimize(unsigned int start_frame_id, unsigned int end_frame_id)
+{
+    m_status = SOSLAM_OK;
+    m_summary = soslam_ba_summary{};
+    if (end_frame_id > m_cam_frames.size()) end_frame_id = (unsigned int)m_cam_frames.size();
+    if (start_frame_id >= end_frame_id) return;
+    const uint32_t n_cam = end_frame_id - start_frame_id;
+
+    std::vector<double> poses((size_t)n_cam * 6);
+    std::vector<double> points;
+    std::vector<unsigned int> point_ids;
+    std::unordered_map<unsigned int, uint32_t> glb_to_local;
+    std::vector<uint32_t> obs_cam, obs_pt;
+    std::vector<float> obs_uv;
+
+    for (uint32_t c = 0; c < n_cam; c++) {
+        const Frame* frame = m_cam_frames[start_frame_id + c];
+        std::array<double, 6> pose;
+        soslam_host::MatrixToPose(frame->GlobalPose().inverse(), pose);
+        for (int a = 0; a < 6; a++) poses[6 * (size_t)c + a] = pose[a];
+        for (const Observation& obs : frame->Observations()) {
+            auto it = glb_to_local.find(obs.point_id);
+            uint32_t local;
+            if (it == glb_to_local.end()) {
+                local = (uint32_t)point_ids.size();
+                glb_to_local.emplace(obs.point_id, local);
+                point_ids.push_back(obs.point_id);
+                const std::array<float, 3> p = m_ldm_points[obs.point_id]->Position();
+                points.push_back(p[0]); points.push_back(p[1]); points.push_back(p[2]);
+            } else {
+                local = it->second;
+            }
+            obs_cam.push_back(c);
+            obs_pt.push_back(local);
+            obs_uv.push_back(obs.u_l); obs_uv.push_back(obs.v_l); obs_uv.push_back(obs.u_r); obs_uv.push_back(obs.v_r);
+        }
+    }
+    std::vector<uint8_t> fixed(n_cam, 0);
+    fixed[0] = 1;
+
+    m_status = soslam_ba_optimize(&m_options, ReprojectionError::p_l.data(), ReprojectionError::p_r.data(), n_cam, poses.data(),
+                                  (uint32_t)point_ids.size(), points.data(), (uint32_t)obs_cam.size(), obs_cam.data(),
+                                  obs_pt.data(), obs_uv.data(), fixed.data(), &m_summary);
+    if (m_status != SOSLAM_OK) {
+        // the caller's map state is left untouched on failure (failure handling)
+        std::fprintf(stderr, "[FAIL]: bundle adjustment failed: %s (%s)\n", soslam_status_string(m_status), soslam_last_error());
+        return;
+    }
+    if (m_options.verbose)
+        std::printf("[INFO]: BA %u frames / %zu points / %zu observations: cost %.6e -> %.6e in %d iterations (%d accepted), %.3f ms\n",
+                    n_cam, point_ids.size(), obs_cam.size(), m_summary.initial_cost, m_summary.final_cost, m_summary.iterations,
+                    m_summary.accepted, 1e3 * m_summary.solve_seconds);
+
+    for (uint32_t c = 0; c < n_cam; c++) {
+        std::array<double, 6> pose;
+        for (int a = 0; a < 6; a++) pose[a] = poses[6 * (size_t)c + a];
+        soslam_host::Mat4f t_cw;
+        soslam_host::PoseToMatrix(pose, t_cw);
+        m_cam_frames[start_frame_id + c]->GlobalPose(t_cw.inverse());
+    }
+    for (size_t i = 0; i < point_ids.size(); i++)
+        m_ldm_points[point_ids[i]]->Position(std::array<double, 3>{points[3 * i], points[3 * i + 1], points[3 * i + 2]});
+}

@@ -1,0 +1,31 @@
+// bundle_adjuster.h - host shim with the reference's entry point
+//   BundleAdjuster(std::vector<Frame*>&, std::vector<MapPoint*>&); void Optimize(unsigned start, unsigned end);
+// (/root/reference/src/bundle_adjuster.h:13-25).  Everything ceres::Solve did is behind soslam_ba_optimize.
+#pragma once
+
+#include <vector>
+
+#include "camera_frame.h"
+#include "map_point.h"
+#include "observation.h"
+#include "soslam_ba.h"
+
+class BundleAdjuster {
+public:
+    BundleAdjuster(std::vector<Frame*>& cam_frames, std::vector<MapPoint*>& ldm_points);
+
+    // window [start_frame_id, end_frame_id): first pose of the window constant, every observed point free
+    void Optimize(unsigned int start_frame_id, unsigned int end_frame_id);
+
+    // extensions (the reference returns void and prints Ceres' report)
+    soslam_ba_options& Options() { return m_options; }
+    const soslam_ba_summary& LastSummary() const { return m_summary; }
+    int LastStatus() const { return m_status; }
+
+private:
+    std::vector<Frame*>& m_cam_frames;
+    std::vector<MapPoint*>& m_ldm_points;
+    soslam_ba_options m_options;
+    soslam_ba_summary m_summary{};
+    int m_status = 0;
+};
