@@ -96,6 +96,8 @@ def lib():
     L.oracle_ba_step.restype = C.c_int
     L.oracle_ba_step_sharded.argtypes = [C.c_uint32] + prob + [C.c_double, C.c_void_p, C.c_void_p]
     L.oracle_ba_step_sharded.restype = C.c_int
+    L.oracle_ba_shard_system.argtypes = [C.c_uint32, C.c_uint32] + prob + [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_ba_shard_system.restype = C.c_int
     L.oracle_ba_solve.argtypes = prob + [C.POINTER(BaSummary), C.c_void_p]
     L.oracle_ba_solve.restype = C.c_int
     if hasattr(L, "oracle_pg_solve"):
@@ -183,6 +185,20 @@ def step(obs_cam, obs_pt, obs_uv, cams, pts, pl, pr, fixed, radius, opts=None, n
     if rc:
         raise RuntimeError(f"oracle_ba_step failed: {rc}")
     return dict(S=S, rhs=rhs, dc=dc, dp=dp, cost=sc[0], model_cost_change=sc[1], candidate_cost=sc[2], step_norm=sc[3])
+
+
+def shard_system(rank, n_rank, obs_cam, obs_pt, obs_uv, cams, pts, pl, pr, fixed, radius, opts=None):
+    """One rank's pre-reduction payload of a point-sharded job: dict(S, rhs, diag)."""
+    oc, op, uv, cams, pts, pl, pr = _prep(obs_cam, obs_pt, obs_uv, cams, pts, pl, pr)
+    opts = opts or default_options()
+    fx = np.ascontiguousarray(fixed, np.uint8)
+    nf = int(len(cams) - fx.sum())
+    S, rhs, diag = np.zeros((6 * nf, 6 * nf)), np.zeros(6 * nf), np.zeros(6 * nf)
+    rc = lib().oracle_ba_shard_system(rank, n_rank, len(cams), len(pts), len(oc), oc, op, uv, cams, pts, pl, pr, _ptr(fx),
+                                      C.byref(opts), radius, _ptr(S), _ptr(rhs), _ptr(diag))
+    if rc:
+        raise RuntimeError(f"oracle_ba_shard_system failed: {rc}")
+    return dict(S=S, rhs=rhs, diag=diag)
 
 
 def solve(obs_cam, obs_pt, obs_uv, cams, pts, pl, pr, fixed, opts=None):

@@ -651,6 +651,52 @@ int oracle_ba_step(uint32_t n_cam, uint32_t n_pt, uint32_t n_obs,
     return rc;
 }
 
+/* one rank's pre-reduction payload: its points' Schur contribution plus its own observations' camera blocks */
+static int shard_partial(ws_t* w, uint32_t p0, uint32_t p1, double* Sr, double* rr, double* diag)
+{
+    const size_t n6 = (size_t)w->n_free * 6;
+    memset(Sr, 0, sizeof(double) * n6 * n6);
+    memset(rr, 0, sizeof(double) * n6);
+    if (diag) memset(diag, 0, sizeof(double) * n6);
+    int rc = schur_accumulate(w, p0, p1, Sr, rr, NULL);
+    for (uint32_t p = p0; p < p1; p++)
+        for (uint32_t q = w->pt_start[p]; q < w->pt_start[p + 1]; q++) {
+            const uint32_t k = w->pt_obs[q];
+            const int32_t f = w->free_idx[w->obs_cam[k]];
+            if (f < 0) continue;
+            const double* jc = w->jc + 24 * (size_t)k; const double* r = w->r + 4 * (size_t)k;
+            for (int i = 0; i < 4; i++)
+                for (int a = 0; a < 6; a++) {
+                    rr[6 * (size_t)f + a] -= jc[i * 6 + a] * r[i];
+                    if (diag) diag[6 * (size_t)f + a] += jc[i * 6 + a] * jc[i * 6 + a];
+                    for (int b = a; b < 6; b++) Sr[(6 * (size_t)f + a) * n6 + 6 * (size_t)f + b] += jc[i * 6 + a] * jc[i * 6 + b];
+                }
+        }
+    return rc;
+}
+
+int oracle_ba_shard_system(uint32_t rank, uint32_t n_rank, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs,
+                           const uint32_t* obs_cam, const uint32_t* obs_pt, const float* obs_uv,
+                           const double* cams, const double* pts, const double* pl, const double* pr,
+                           const uint8_t* cam_fixed, const oracle_ba_options* opt, double radius,
+                           double* s_partial, double* rhs_partial, double* diag_partial)
+{
+    ws_t w;
+    set_threads(opt);
+    if (n_rank == 0 || rank >= n_rank) return -1;
+    if (ws_init(&w, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_uv, pl, pr, cam_fixed, opt) != 0) return -1;
+    oracle_ba_linearize(n_obs, obs_cam, obs_pt, obs_uv, cams, pts, pl, pr, cam_fixed, opt->huber_delta, w.r, w.jc, w.jp);
+    build_normal(&w);
+    compute_scale(&w);    /* point scales are rank-local (all observations of a point live on one rank) */
+    compute_damping(&w, radius);
+    const uint32_t p0 = (uint32_t)(((uint64_t)rank * n_pt) / n_rank), p1 = (uint32_t)(((uint64_t)(rank + 1) * n_pt) / n_rank);
+    int rc = shard_partial(&w, p0, p1, s_partial, rhs_partial, diag_partial);
+    const size_t n6 = (size_t)w.n_free * 6;
+    for (size_t i = 0; i < n6; i++) for (size_t j = 0; j < i; j++) s_partial[i * n6 + j] = s_partial[j * n6 + i];
+    ws_free(&w);
+    return rc;
+}
+
 int oracle_ba_step_sharded(uint32_t n_rank, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs,
                            const uint32_t* obs_cam, const uint32_t* obs_pt, const float* obs_uv,
                            const double* cams, const double* pts, const double* pl, const double* pr,
@@ -673,21 +719,7 @@ int oracle_ba_step_sharded(uint32_t n_rank, uint32_t n_cam, uint32_t n_pt, uint3
     int rc = 0;
     for (uint32_t rank = 0; rank < n_rank && rc == 0; rank++) {
         const uint32_t p0 = (uint32_t)(((uint64_t)rank * n_pt) / n_rank), p1 = (uint32_t)(((uint64_t)(rank + 1) * n_pt) / n_rank);
-        memset(Sr, 0, sizeof(double) * n6 * n6); memset(rr, 0, sizeof(double) * n6);
-        rc = schur_accumulate(&w, p0, p1, Sr, rr, NULL);
-        /* the rank's share of the camera blocks: its own observations only */
-        for (uint32_t p = p0; p < p1; p++)
-            for (uint32_t q = w.pt_start[p]; q < w.pt_start[p + 1]; q++) {
-                const uint32_t k = w.pt_obs[q];
-                const int32_t f = w.free_idx[obs_cam[k]];
-                if (f < 0) continue;
-                const double* jc = w.jc + 24 * (size_t)k; const double* r = w.r + 4 * (size_t)k;
-                for (int i = 0; i < 4; i++)
-                    for (int a = 0; a < 6; a++) {
-                        rr[6 * (size_t)f + a] -= jc[i * 6 + a] * r[i];
-                        for (int b = a; b < 6; b++) Sr[(6 * (size_t)f + a) * n6 + 6 * (size_t)f + b] += jc[i * 6 + a] * jc[i * 6 + b];
-                    }
-            }
+        rc = shard_partial(&w, p0, p1, Sr, rr, NULL);
         for (size_t i = 0; i < n6 * n6; i++) Ssum[i] += Sr[i];   /* the all-reduce */
         for (size_t i = 0; i < n6; i++) rsum[i] += rr[i];
     }

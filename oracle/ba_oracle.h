@@ -142,6 +142,18 @@ int oracle_ba_step_sharded(uint32_t n_rank, uint32_t n_cam, uint32_t n_pt, uint3
                            const uint8_t* cam_fixed, const oracle_ba_options* opt, double radius,
                            double* s_dense, double* rhs);
 
+/*
+ * What ONE rank of a point-sharded job contributes before the all-reduce: the dense reduced-system partial
+ * (no camera damping: that is added after the reduction from the reduced diagonal), its right-hand side and
+ * the diagonal of its camera blocks.  Summing the outputs over rank = 0..n_rank-1 and adding the camera
+ * damping gives oracle_ba_step's s_dense / rhs.
+ */
+int oracle_ba_shard_system(uint32_t rank, uint32_t n_rank, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs,
+                           const uint32_t* obs_cam, const uint32_t* obs_pt, const float* obs_uv,
+                           const double* cams, const double* pts, const double* proj_l, const double* proj_r,
+                           const uint8_t* cam_fixed, const oracle_ba_options* opt, double radius,
+                           double* s_partial, double* rhs_partial, double* diag_partial);
+
 #ifdef __cplusplus
 }
 #endif
