@@ -310,6 +310,65 @@ def gen_pg_edge(rng: np.random.Generator):
     print("pg_edge_jacobian.npz:", len(es), "cases")
 
 
+def gen_pg_minimum_scipy(rng: np.random.Generator):
+    """Small pose graph (chain + loop edges) minimised by scipy over [t, rotation-vector] per vertex; the robust
+    objective sum rho(e^T Omega e) is parametrisation-independent, so its minimum pins the g2o-style solver."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    n = 24
+    truth = np.zeros((n, 7))
+    for i in range(n):
+        ang = 2 * np.pi * i / n
+        truth[i, :3] = [6 * np.cos(ang), 6 * np.sin(ang), 0.3 * np.sin(2 * ang)]
+        truth[i, 3:] = Rotation.from_euler("zyx", [ang + np.pi / 2, 0.05 * np.sin(ang), 0.03 * np.cos(ang)]).as_quat()
+    edges = [(i, i + 1) for i in range(n - 1)] + [(n - 1, 0), (12, 0), (18, 6), (20, 3)]   # (from, to)
+    meas = []
+    for a, b in edges:
+        Ra, Rb = Rotation.from_quat(truth[a, 3:]), Rotation.from_quat(truth[b, 3:])
+        Rz = Ra.inv() * Rb * Rotation.from_rotvec(rng.normal(0, 0.01, 3))
+        tz = Ra.inv().apply(truth[b, :3] - truth[a, :3]) + rng.normal(0, 0.05, 3)
+        q = Rz.as_quat()
+        meas.append(np.concatenate([tz, q if q[3] >= 0 else -q]))
+    meas = np.array(meas)
+    meas[-1, :3] += [20.0, -15.0, 5.0]                   # one gross outlier (chi2 > 1): the Huber branch
+    est0 = truth.copy()
+    for i in range(1, n):
+        est0[i, :3] += rng.normal(0, 0.15, 3)
+        est0[i, 3:] = (Rotation.from_quat(truth[i, 3:]) * Rotation.from_rotvec(rng.normal(0, 0.04, 3))).as_quat()
+    info = np.diag([0.01, 0.01, 0.01, 1.0, 1.0, 1.0])
+    Lw = np.sqrt(info)
+
+    def edge_err(xa, xb, z):
+        return pg_edge_error(torch.tensor(xa), torch.tensor(xb), torch.tensor(z), torch.zeros(6), torch.zeros(6)).numpy()
+
+    def unpack(v):
+        est = np.zeros((n, 7))
+        est[0] = est0[0]
+        for i in range(1, n):
+            est[i, :3] = v[6 * (i - 1):6 * (i - 1) + 3]
+            q = Rotation.from_rotvec(v[6 * (i - 1) + 3:6 * i]).as_quat()
+            est[i, 3:] = q
+        return est
+
+    def fun(v):
+        est = unpack(v)
+        out = []
+        for k, (a, b) in enumerate(edges):
+            e = edge_err(est[a], est[b], meas[k])
+            chi = float(e @ info @ e)
+            rho = chi if chi <= 1.0 else 2 * np.sqrt(chi) - 1.0
+            out.append(Lw @ e * np.sqrt(rho / max(chi, 1e-300)))
+        return np.concatenate(out)
+
+    v0 = np.concatenate([np.concatenate([est0[i, :3], Rotation.from_quat(est0[i, 3:]).as_rotvec()]) for i in range(1, n)])
+    sol = least_squares(fun, v0, method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-12, max_nfev=400)
+    est = unpack(sol.x)
+    np.savez(os.path.join(OUT, "pg_minimum_scipy.npz"), est0=est0, e_from=np.array([a for a, _ in edges], np.uint32),
+             e_to=np.array([b for _, b in edges], np.uint32), meas=meas, info=info.reshape(36), est=est, chi2=2 * sol.cost,
+             chi2_0=float((fun(v0) ** 2).sum()))
+    print("pg_minimum_scipy.npz: chi2", float((fun(v0) ** 2).sum()), "->", 2 * sol.cost, "status", sol.status, "nfev", sol.nfev)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20241004)
@@ -317,6 +376,7 @@ def main():
     prob = gen_step_dense(rng)
     gen_minimum_scipy(prob)
     gen_pg_edge(rng)
+    gen_pg_minimum_scipy(rng)
 
 
 if __name__ == "__main__":
