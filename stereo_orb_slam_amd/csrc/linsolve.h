@@ -71,3 +71,19 @@ void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band
                      const double* b, double* x, double* resid, double* work, double tol, int max_rounds, double* scal);
 
 }  // namespace soslam
+
+namespace soslam {
+
+// ---- multi-workgroup block-Jacobi PCG on (A + shift I) ---------------------------------------------------
+// For systems too large or too irregular for the band factor (pose graphs with loop closures, BA with a wide
+// co-visibility pattern).  Every vector operation and the product with A run over many workgroups; the two
+// reductions of an iteration are per-workgroup partials summed redundantly (fixed order) by every workgroup
+// of the next kernel, so there is no single-CU stage and no host round trip inside a chunk of iterations.
+size_t pcg_multi_work_count(uint32_t n_rows);   // f64 of caller-provided work space
+// Runs until |r| <= tol |b| or max_iter; synchronises the stream once per `chunk` iterations to read the
+// device-side state.  Returns iterations done (>= 0) or -1 on breakdown; *rel_resid receives |r|/|b|.
+// resid (required: it is the iteration's residual vector) receives the final b - (A + shift I) x.
+int pcg_multi_solve(hipStream_t s, const BsrView& A, double shift, const double* b, double* x, double* resid,
+                    double* work, double tol, int max_iter, int chunk, double* rel_resid);
+
+}  // namespace soslam

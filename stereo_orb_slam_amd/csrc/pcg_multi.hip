@@ -1,0 +1,289 @@
+// pcg_multi.hip - multi-workgroup block-Jacobi PCG on a block-sparse symmetric matrix (6x6 blocks) + shift.
+//
+// Three kernels per iteration, each over ceil(n_rows / 42) workgroups of 256 lanes (42 block rows = 252 scalar
+// rows per workgroup):
+//   matvec     q = (A + shift I) p, partial p.q
+//   update     alpha from the partials; x += alpha p; r -= alpha q; z = M^-1 r; partial r.z and r.r
+//   direction  beta from the partials; p = z + beta p
+// Partials are double-buffered by iteration parity; every workgroup sums them in the same fixed order, so all
+// agree bit for bit on alpha, beta and on convergence, and a converged solve turns the remaining launches of a
+// chunk into immediate returns.
+#include "linsolve.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace soslam {
+
+namespace {
+
+constexpr int kRowsPerWg = 42;   // block rows per workgroup
+constexpr int kThreads = 256;
+enum { ST_BB = 0, ST_ITERS = 1, ST_BREAKDOWN = 2, ST_COUNT = 4 };
+
+struct PcgBufs {
+    double *p, *z, *q, *minv, *part_pq, *part_rz, *part_rr, *state;   // part_rz / part_rr: [2][n_wg]
+    uint32_t n_wg;
+};
+
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, uint32_t n)
+{
+    double s = 0.0;
+    for (uint32_t i = 0; i < n; i++) s += part[i];
+    return s;
+}
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+__device__ __forceinline__ double block_sum256(double v, double* red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if (threadIdx.x % 64 == 0) red[threadIdx.x / 64] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ bool spd6_inverse_shift(const double* __restrict__ A, double shift, double* __restrict__ out)
+{
+    double L[6][6], Li[6][6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+#pragma unroll
+        for (int i = j; i < 6; i++) {
+            double s = A[i * 6 + j] + (i == j ? shift : 0.0);
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+            if (i == j) { ok = ok && (s > 0.0); L[j][j] = sqrt(s); } else L[i][j] = s / L[j][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        Li[j][j] = 1.0 / L[j][j];
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = j; k < i; k++) s -= L[i][k] * Li[k][j];
+            Li[i][j] = s / L[i][i];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = a; b < 6; b++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = b; k < 6; k++) s += Li[k][a] * Li[k][b];
+            out[a * 6 + b] = s;
+            out[b * 6 + a] = s;
+        }
+    return ok;
+}
+
+__device__ __forceinline__ double bsr_row_dot(const BsrView& A, uint32_t row, const double* __restrict__ v)
+{
+    const uint32_t f = row / 6, a = row % 6;
+    double s = 0.0;
+    for (uint32_t e = A.row_ptr[f]; e < A.row_ptr[f + 1]; e++) {
+        const double* B = A.blocks + 36 * (size_t)A.ent_blk[e];
+        const double* x = v + 6 * (size_t)A.ent_col[e];
+        if (A.ent_trans[e]) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) s += B[c * 6 + a] * x[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) s += B[a * 6 + c] * x[c];
+        }
+    }
+    return s;
+}
+
+// x = 0, r = b, M = blockdiag(A + shift I)^-1, z = M r, p = z; partials of b.b (-> rr parity 0) and r.z (parity 0)
+__global__ __launch_bounds__(kThreads) void pcgm_init_kernel(const BsrView A, const double shift, const double* __restrict__ b,
+                                                             double* __restrict__ x, double* __restrict__ r, const PcgBufs w)
+{
+    __shared__ double red[4];
+    __shared__ double rloc[kRowsPerWg * 6];
+    const uint32_t n = A.n_rows * 6;
+    const uint32_t row0 = blockIdx.x * kRowsPerWg * 6;
+    const int t = threadIdx.x;
+    const uint32_t i = row0 + t;
+    const bool act = t < kRowsPerWg * 6 && i < n;
+    if (t < kRowsPerWg) {
+        const uint32_t f = blockIdx.x * kRowsPerWg + t;
+        if (f < A.n_rows && !spd6_inverse_shift(A.blocks + 36 * (size_t)A.diag_block[f], shift, w.minv + 36 * (size_t)f))
+            w.state[ST_BREAKDOWN] = 1.0;
+    }
+    double bi = 0.0;
+    if (act) { bi = b[i]; x[i] = 0.0; r[i] = bi; rloc[t] = bi; }
+    __syncthreads();
+    double rz = 0.0;
+    if (act) {
+        const double* M = w.minv + 36 * (size_t)(i / 6) + 6 * (i % 6);
+        const double* rv = rloc + (t / 6) * 6;
+        const double zi = M[0] * rv[0] + M[1] * rv[1] + M[2] * rv[2] + M[3] * rv[3] + M[4] * rv[4] + M[5] * rv[5];
+        w.z[i] = zi;
+        w.p[i] = zi;
+        rz = bi * zi;
+    }
+    const double bb = block_sum256(bi * bi, red);
+    rz = block_sum256(rz, red);
+    if (t == 0) {
+        w.part_rr[blockIdx.x] = bb;
+        w.part_rz[blockIdx.x] = rz;
+        if (blockIdx.x == 0) { w.state[ST_ITERS] = 0.0; }
+    }
+}
+
+// |b|^2 is the parity-0 rr of the init kernel; keep a copy that survives the iterations
+__global__ void pcgm_bb_kernel(const PcgBufs w)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) w.state[ST_BB] = sum_partials(w.part_rr, w.n_wg);
+}
+
+__device__ __forceinline__ bool converged(const PcgBufs& w, int parity, double tol)
+{
+    const double rr = sum_partials(w.part_rr + parity * w.n_wg, w.n_wg);
+    const double bb = w.state[ST_BB];
+    return !(rr > tol * tol * bb) || w.state[ST_BREAKDOWN] != 0.0;
+}
+
+__global__ __launch_bounds__(kThreads) void pcgm_matvec_kernel(const BsrView A, const double shift, const PcgBufs w,
+                                                               const int parity, const double tol)
+{
+    __shared__ double red[4];
+    if (converged(w, parity, tol)) return;
+    const uint32_t n = A.n_rows * 6;
+    const int t = threadIdx.x;
+    const uint32_t i = blockIdx.x * kRowsPerWg * 6 + t;
+    double pq = 0.0;
+    if (t < kRowsPerWg * 6 && i < n) {
+        const double pi = w.p[i];
+        const double qi = bsr_row_dot(A, i, w.p) + shift * pi;
+        w.q[i] = qi;
+        pq = pi * qi;
+    }
+    pq = block_sum256(pq, red);
+    if (t == 0) w.part_pq[blockIdx.x] = pq;
+}
+
+__global__ __launch_bounds__(kThreads) void pcgm_update_kernel(const uint32_t n, double* __restrict__ x, double* __restrict__ r,
+                                                               const PcgBufs w, const int parity, const double tol)
+{
+    __shared__ double red[4];
+    __shared__ double rloc[kRowsPerWg * 6];
+    if (converged(w, parity, tol)) return;
+    const double pq = sum_partials(w.part_pq, w.n_wg);
+    const double rz = sum_partials(w.part_rz + parity * w.n_wg, w.n_wg);
+    const int t = threadIdx.x;
+    if (!(pq > 0.0)) {
+        if (t == 0 && blockIdx.x == 0) w.state[ST_BREAKDOWN] = 2.0;
+        return;
+    }
+    const double alpha = rz / pq;
+    const uint32_t i = blockIdx.x * kRowsPerWg * 6 + t;
+    const bool act = t < kRowsPerWg * 6 && i < n;
+    double ri = 0.0;
+    if (act) {
+        x[i] += alpha * w.p[i];
+        ri = r[i] - alpha * w.q[i];
+        r[i] = ri;
+        rloc[t] = ri;
+    }
+    __syncthreads();
+    double rzn = 0.0;
+    if (act) {
+        const double* M = w.minv + 36 * (size_t)(i / 6) + 6 * (i % 6);
+        const double* rv = rloc + (t / 6) * 6;
+        const double zi = M[0] * rv[0] + M[1] * rv[1] + M[2] * rv[2] + M[3] * rv[3] + M[4] * rv[4] + M[5] * rv[5];
+        w.z[i] = zi;
+        rzn = ri * zi;
+    }
+    const double rr = block_sum256(ri * ri, red);
+    rzn = block_sum256(rzn, red);
+    if (t == 0) {
+        w.part_rr[(parity ^ 1) * w.n_wg + blockIdx.x] = rr;
+        w.part_rz[(parity ^ 1) * w.n_wg + blockIdx.x] = rzn;
+        if (blockIdx.x == 0) w.state[ST_ITERS] += 1.0;
+    }
+}
+
+// parity = parity BEFORE the update kernel of this iteration; the new sums sit at parity ^ 1
+__global__ __launch_bounds__(kThreads) void pcgm_direction_kernel(const uint32_t n, const PcgBufs w, const int parity, const double tol)
+{
+    // the update kernel ran iff the system had not converged at `parity`; it may have converged now - p is then unused
+    if (converged(w, parity, tol)) return;
+    const double rz_old = sum_partials(w.part_rz + parity * w.n_wg, w.n_wg);
+    const double rz_new = sum_partials(w.part_rz + (parity ^ 1) * w.n_wg, w.n_wg);
+    const double beta = rz_new / rz_old;
+    const int t = threadIdx.x;
+    const uint32_t i = blockIdx.x * kRowsPerWg * 6 + t;
+    if (t < kRowsPerWg * 6 && i < n) w.p[i] = w.z[i] + beta * w.p[i];
+}
+
+}  // namespace
+
+size_t pcg_multi_work_count(uint32_t n_rows)
+{
+    const size_t n = (size_t)n_rows * 6, n_wg = (n_rows + kRowsPerWg - 1) / kRowsPerWg;
+    return 3 * n + 36 * (size_t)n_rows + 5 * n_wg + ST_COUNT + 16;
+}
+
+int pcg_multi_solve(hipStream_t s, const BsrView& A, double shift, const double* b, double* x, double* resid,
+                    double* work, double tol, int max_iter, int chunk, double* rel_resid)
+{
+    if (rel_resid) *rel_resid = 0.0;
+    if (!A.n_rows) return 0;
+    const uint32_t n = A.n_rows * 6, n_wg = (A.n_rows + kRowsPerWg - 1) / kRowsPerWg;
+    PcgBufs w;
+    w.n_wg = n_wg;
+    w.p = work; w.z = w.p + n; w.q = w.z + n; w.minv = w.q + n;
+    w.part_pq = w.minv + 36 * (size_t)A.n_rows;
+    w.part_rz = w.part_pq + n_wg;
+    w.part_rr = w.part_rz + 2 * (size_t)n_wg;
+    w.state = w.part_rr + 2 * (size_t)n_wg;
+    if (!resid) return -2;   // the residual vector is part of the iteration state
+    double* r = resid;
+    (void)hipMemsetAsync(w.state, 0, sizeof(double) * ST_COUNT, s);
+    hipLaunchKernelGGL(pcgm_init_kernel, dim3(n_wg), dim3(kThreads), 0, s, A, shift, b, x, r, w);
+    hipLaunchKernelGGL(pcgm_bb_kernel, dim3(1), dim3(64), 0, s, w);
+    int parity = 0, launched = 0;
+    double host_state[ST_COUNT] = {0, 0, 0, 0};
+    double rr = 0.0;
+    while (launched < max_iter) {
+        const int todo = std::min(chunk, max_iter - launched);
+        for (int k = 0; k < todo; k++) {
+            hipLaunchKernelGGL(pcgm_matvec_kernel, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, parity, tol);
+            hipLaunchKernelGGL(pcgm_update_kernel, dim3(n_wg), dim3(kThreads), 0, s, n, x, r, w, parity, tol);
+            hipLaunchKernelGGL(pcgm_direction_kernel, dim3(n_wg), dim3(kThreads), 0, s, n, w, parity, tol);
+            parity ^= 1;
+        }
+        launched += todo;
+        // one round trip per chunk: iterations done, |b|^2, breakdown flag, and the current |r|^2 partials
+        std::vector<double> rrp(2 * (size_t)n_wg);
+        if (hipMemcpyAsync(host_state, w.state, sizeof host_state, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipMemcpyAsync(rrp.data(), w.part_rr, sizeof(double) * rrp.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        if (host_state[ST_BREAKDOWN] != 0.0) return -1;
+        const int done = (int)host_state[ST_ITERS];
+        const int par = done & 1;   // parity after `done` updates
+        rr = 0.0;
+        for (uint32_t i = 0; i < n_wg; i++) rr += rrp[(size_t)par * n_wg + i];
+        if (!(rr > tol * tol * host_state[ST_BB]) || done < launched) {
+            if (rel_resid) *rel_resid = host_state[ST_BB] > 0 ? std::sqrt(rr / host_state[ST_BB]) : 0.0;
+            return done;
+        }
+    }
+    if (rel_resid) *rel_resid = host_state[ST_BB] > 0 ? std::sqrt(rr / host_state[ST_BB]) : 0.0;
+    return (int)host_state[ST_ITERS];
+}
+
+}  // namespace soslam

@@ -1,0 +1,29 @@
+// pg_kernels.h - launch wrappers of the pose-graph kernels (definitions in pg_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace soslam {
+
+struct PgInfo { double m[36]; };   // shared information matrix, row-major
+
+// where edge k scatters its blocks: free indices of its vertices (-1 = fixed), block ids in the upper
+// block-sparse H, and whether the stored off-diagonal block is H(j,i) (fj < fi) or H(i,j)
+struct PgEdgeBlocks {
+    int32_t fi, fj, diag_i, diag_j, off, off_is_ji;
+};
+
+void launch_pg_linearize(hipStream_t s, uint32_t n_edge, const double* est, const uint32_t* ef, const uint32_t* et,
+                         const double* meas, const PgInfo& info, double delta, const PgEdgeBlocks* eb, double* H, double* b,
+                         double* chi_part, double* dbg_e, double* dbg_ji, double* dbg_jj);
+void launch_pg_chi2(hipStream_t s, uint32_t n_edge, const double* est, const uint32_t* ef, const uint32_t* et,
+                    const double* meas, const PgInfo& info, double delta, double* chi_part);
+// out[0] = sum(part[0..n)); if diag_block: out[1] = max |diag(H)|
+void launch_pg_reduce(hipStream_t s, const double* part, uint32_t n, const double* H, const int32_t* diag_block, uint32_t n_free,
+                      double* out);
+void launch_pg_update(hipStream_t s, uint32_t n_vertex, const double* est, const int32_t* free_idx, const double* x,
+                      const double* b, double lambda, double* cand, double* scale_part);
+
+}  // namespace soslam

@@ -1,1 +1,431 @@
-// placeholder
+// pg_solver.hip - host side of the pose-graph backend: block pattern of H from the edge list, device state, g2o's
+// Levenberg controller (OptimizationAlgorithmLevenberg::solve) and the C ABI of
+// include/soslam_pg.h.  Replaces m_optimizer.initializeOptimization(); m_optimizer.optimize(10)
+// (/root/reference/src/pose_graph_optimizer.cpp:68-69).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <memory>
+
+#include "common.h"
+#include "linsolve.h"
+#include "pg_kernels.h"
+#include "soslam_pg.h"
+
+using namespace soslam;
+
+struct soslam_pg {
+    soslam_pg_options opt{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int device = 0;
+    bool have_graph = false;
+    uint32_t n_vertex = 0, n_edge = 0, n_free = 0, n_blocks = 0, n_chi_part = 0, n_scale_part = 0;
+    PgInfo info{};
+    std::vector<int32_t> h_free;
+    std::vector<uint32_t> h_blk_row, h_blk_col;
+    DevBuf<double> est[2], meas, H, b, x, resid, work, chi_part, chi_part_lin, scale_part, scal;
+    DevBuf<uint32_t> ef, et, row_ptr, ent_col, ent_blk;
+    DevBuf<uint8_t> ent_trans;
+    DevBuf<int32_t> free_idx, diag_block;
+    DevBuf<PgEdgeBlocks> eb;
+    int cur = 0;
+    double setup_seconds = 0.0;
+    std::vector<soslam_pg_iteration> log;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+
+    ~soslam_pg()
+    {
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+double now_sec()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+BsrView bsr_view(const soslam_pg* h)
+{
+    return BsrView{h->n_free, h->row_ptr.p, h->ent_col.p, h->ent_blk.p, h->ent_trans.p, h->diag_block.p, h->H.p};
+}
+
+int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_t* fixed, uint32_t n_edge, const uint32_t* ef,
+                const uint32_t* et, const double* meas, const double* info)
+{
+    const double t0 = now_sec();
+    hipStream_t s = h->stream;
+    for (uint32_t k = 0; k < n_edge; k++)
+        if (ef[k] >= n_vertex || et[k] >= n_vertex || ef[k] == et[k]) {
+            set_last_error("edge %u (%u -> %u) is out of range or a self loop", k, ef[k], et[k]);
+            return SOSLAM_ERR_INVALID_ARGUMENT;
+        }
+    h->n_vertex = n_vertex; h->n_edge = n_edge;
+    std::memcpy(h->info.m, info, sizeof h->info.m);
+    h->h_free.assign(n_vertex, -1);
+    uint32_t nf = 0;
+    for (uint32_t v = 0; v < n_vertex; v++)
+        if (!(fixed && fixed[v])) h->h_free[v] = (int32_t)nf++;
+    h->n_free = nf;
+
+    // upper block pattern: diagonal + one block per connected pair of free vertices
+    std::vector<std::vector<uint32_t>> rows(nf);
+    for (uint32_t f = 0; f < nf; f++) rows[f].push_back(f);
+    for (uint32_t k = 0; k < n_edge; k++) {
+        const int32_t a = h->h_free[ef[k]], b = h->h_free[et[k]];
+        if (a >= 0 && b >= 0) rows[std::min(a, b)].push_back((uint32_t)std::max(a, b));
+    }
+    std::vector<uint32_t> row_first(nf + 1, 0);
+    for (uint32_t f = 0; f < nf; f++) {
+        std::sort(rows[f].begin(), rows[f].end());
+        rows[f].erase(std::unique(rows[f].begin(), rows[f].end()), rows[f].end());
+        row_first[f + 1] = row_first[f] + (uint32_t)rows[f].size();
+    }
+    h->n_blocks = row_first[nf];
+    h->h_blk_row.resize(h->n_blocks); h->h_blk_col.resize(h->n_blocks);
+    std::vector<int32_t> diag_block(nf);
+    for (uint32_t f = 0; f < nf; f++)
+        for (size_t e = 0; e < rows[f].size(); e++) {
+            const uint32_t blk = row_first[f] + (uint32_t)e;
+            h->h_blk_row[blk] = f; h->h_blk_col[blk] = rows[f][e];
+            if (rows[f][e] == f) diag_block[f] = (int32_t)blk;
+        }
+    auto find_block = [&](uint32_t i, uint32_t j) -> int32_t {
+        const auto& r = rows[i];
+        auto it = std::lower_bound(r.begin(), r.end(), j);
+        return (int32_t)(row_first[i] + (uint32_t)(it - r.begin()));
+    };
+    std::vector<PgEdgeBlocks> eb(n_edge);
+    for (uint32_t k = 0; k < n_edge; k++) {
+        const int32_t a = h->h_free[ef[k]], b = h->h_free[et[k]];
+        PgEdgeBlocks e{a, b, a >= 0 ? diag_block[a] : -1, b >= 0 ? diag_block[b] : -1, -1, 0};
+        if (a >= 0 && b >= 0) {
+            e.off = find_block((uint32_t)std::min(a, b), (uint32_t)std::max(a, b));
+            e.off_is_ji = b < a ? 1 : 0;
+        }
+        eb[k] = e;
+    }
+    std::vector<uint32_t> row_ptr(nf + 1, 0), ent_col, ent_blk;
+    std::vector<uint8_t> ent_trans;
+    {
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> full(nf);
+        for (uint32_t blk = 0; blk < h->n_blocks; blk++) {
+            const uint32_t i = h->h_blk_row[blk], j = h->h_blk_col[blk];
+            full[i].push_back({j, blk});
+            if (i != j) full[j].push_back({i, blk | 0x80000000u});
+        }
+        for (uint32_t f = 0; f < nf; f++) {
+            std::sort(full[f].begin(), full[f].end());
+            row_ptr[f + 1] = row_ptr[f] + (uint32_t)full[f].size();
+            for (auto& e : full[f]) {
+                ent_col.push_back(e.first);
+                ent_blk.push_back(e.second & 0x7FFFFFFFu);
+                ent_trans.push_back((uint8_t)(e.second >> 31));
+            }
+        }
+    }
+    h->n_chi_part = div_up(n_edge, 128);
+    h->n_scale_part = div_up(n_vertex, 256);
+    std::vector<double> v_est(est, est + 7 * (size_t)n_vertex), v_meas(meas, meas + 7 * (size_t)n_edge);
+    std::vector<uint32_t> v_ef(ef, ef + n_edge), v_et(et, et + n_edge);
+    SOSLAM_CHECK(h->est[0].upload(v_est, s));
+    SOSLAM_CHECK(h->est[1].alloc(v_est.size()));
+    SOSLAM_CHECK(h->meas.upload(v_meas, s));
+    SOSLAM_CHECK(h->ef.upload(v_ef, s));
+    SOSLAM_CHECK(h->et.upload(v_et, s));
+    SOSLAM_CHECK(h->free_idx.upload(h->h_free, s));
+    SOSLAM_CHECK(h->diag_block.upload(diag_block, s));
+    SOSLAM_CHECK(h->eb.upload(eb, s));
+    SOSLAM_CHECK(h->row_ptr.upload(row_ptr, s));
+    SOSLAM_CHECK(h->ent_col.upload(ent_col, s));
+    SOSLAM_CHECK(h->ent_blk.upload(ent_blk, s));
+    SOSLAM_CHECK(h->ent_trans.upload(ent_trans, s));
+    SOSLAM_CHECK(h->H.alloc((size_t)h->n_blocks * 36));
+    SOSLAM_CHECK(h->b.alloc((size_t)nf * 6));
+    SOSLAM_CHECK(h->x.alloc((size_t)nf * 6));
+    SOSLAM_CHECK(h->x.zero(s));
+    SOSLAM_CHECK(h->resid.alloc((size_t)nf * 6));
+    SOSLAM_CHECK(h->work.alloc(pcg_multi_work_count(nf)));
+    SOSLAM_CHECK(h->chi_part.alloc(std::max<uint32_t>(h->n_chi_part, div_up(n_edge, 256))));
+    SOSLAM_CHECK(h->chi_part_lin.alloc(h->n_chi_part));
+    SOSLAM_CHECK(h->scale_part.alloc(h->n_scale_part));
+    SOSLAM_CHECK(h->scal.alloc(8));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    h->cur = 0;
+    h->have_graph = true;
+    h->setup_seconds = now_sec() - t0;
+    return SOSLAM_OK;
+}
+
+// H, b and the robust chi2 at the current estimates; scal[0] = chi2, scal[1] = max |diag H|
+int linearize(soslam_pg* h, double* dbg_e, double* dbg_ji, double* dbg_jj)
+{
+    hipStream_t s = h->stream;
+    SOSLAM_CHECK(h->H.zero(s));
+    SOSLAM_CHECK(h->b.zero(s));
+    launch_pg_linearize(s, h->n_edge, h->est[h->cur].p, h->ef.p, h->et.p, h->meas.p, h->info, h->opt.huber_delta, h->eb.p, h->H.p,
+                        h->b.p, h->chi_part_lin.p, dbg_e, dbg_ji, dbg_jj);
+    launch_pg_reduce(s, h->chi_part_lin.p, h->n_chi_part, h->H.p, h->diag_block.p, h->n_free, h->scal.p);
+    SOSLAM_HIP_CHECK(hipGetLastError());
+    return SOSLAM_OK;
+}
+
+int read_scal(soslam_pg* h, double* out, int n)
+{
+    SOSLAM_HIP_CHECK(hipMemcpyAsync(out, h->scal.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return SOSLAM_OK;
+}
+
+float elapsed_ms(soslam_pg* h)
+{
+    float ms = 0.0f;
+    (void)hipEventSynchronize(h->ev[1]);
+    (void)hipEventElapsedTime(&ms, h->ev[0], h->ev[1]);
+    return ms;
+}
+
+int run(soslam_pg* h, soslam_pg_summary* out)
+{
+    if (!h->have_graph) { set_last_error("optimize before set_graph"); return SOSLAM_ERR_STATE; }
+    const soslam_pg_options& o = h->opt;
+    hipStream_t s = h->stream;
+    soslam_pg_summary sum{};
+    sum.setup_seconds = h->setup_seconds;
+    sum.termination = SOSLAM_PG_TERM_ITERATIONS;
+    h->log.clear();
+    const double t0 = now_sec();
+    double lambda = 0.0, ni = 2.0, current = 0.0;
+    double sc[4];
+    int it = 0;
+    for (it = 0; it < o.max_iterations; it++) {
+        SOSLAM_HIP_CHECK(hipEventRecord(h->ev[0], s));
+        SOSLAM_CHECK(linearize(h, nullptr, nullptr, nullptr));
+        SOSLAM_HIP_CHECK(hipEventRecord(h->ev[1], s));
+        SOSLAM_CHECK(read_scal(h, sc, 2));
+        sum.linearize_ms += elapsed_ms(h);
+        current = sc[0];
+        if (it == 0) {
+            sum.initial_chi2 = current;
+            if (!std::isfinite(current)) { set_last_error("non-finite chi2 at the initial estimates"); return SOSLAM_ERR_NON_FINITE; }
+            lambda = o.tau * sc[1];
+            ni = 2.0;
+        }
+        double rho = 0.0;
+        int qmax = 0, accepted = 0, lin_total = 0;
+        do {
+            double rel = 0.0;
+            int lin_it = 0;
+            SOSLAM_HIP_CHECK(hipEventRecord(h->ev[0], s));
+            if (h->n_free) lin_it = pcg_multi_solve(s, bsr_view(h), lambda, h->b.p, h->x.p, h->resid.p, h->work.p, o.pcg_tolerance,
+                                                     o.pcg_max_iterations, 32, &rel);
+            SOSLAM_HIP_CHECK(hipEventRecord(h->ev[1], s));
+            const bool ok = lin_it >= 0;
+            lin_total += std::max(lin_it, 0);
+            launch_pg_update(s, h->n_vertex, h->est[h->cur].p, h->free_idx.p, h->x.p, h->b.p, lambda, h->est[h->cur ^ 1].p, h->scale_part.p);
+            launch_pg_reduce(s, h->scale_part.p, h->n_scale_part, nullptr, nullptr, 0, h->scal.p + 2);
+            launch_pg_chi2(s, h->n_edge, h->est[h->cur ^ 1].p, h->ef.p, h->et.p, h->meas.p, h->info, o.huber_delta, h->chi_part.p);
+            launch_pg_reduce(s, h->chi_part.p, div_up(h->n_edge, 256), nullptr, nullptr, 0, h->scal.p + 3);
+            SOSLAM_HIP_CHECK(hipGetLastError());
+            SOSLAM_CHECK(read_scal(h, sc, 4));
+            sum.linear_solve_ms += elapsed_ms(h);
+            double temp = ok ? sc[3] : 1.7976931348623157e308;
+            const double scale = sc[2] + 1e-3;
+            rho = (current - temp) / scale;
+            if (rho > 0 && std::isfinite(temp)) {
+                double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3.0);
+                alpha = std::min(alpha, 2.0 / 3.0);
+                lambda *= std::max(1.0 / 3.0, alpha);
+                ni = 2.0;
+                current = temp;
+                h->cur ^= 1;   // discardTop: keep the candidate
+                accepted = 1;
+            } else {
+                lambda *= ni;   // pop: the current estimates stay
+                ni *= 2.0;
+                if (!std::isfinite(lambda)) break;
+            }
+            qmax++;
+        } while (rho < 0 && qmax < o.max_trials);
+        sum.linear_iterations += lin_total;
+        soslam_pg_iteration e{current, lambda, qmax, accepted, lin_total, 0};
+        h->log.push_back(e);
+        if (o.verbose) std::printf("iteration= %d\t chi2= %.9e\t lambda= %.6e\t levenbergIter= %d\t pcg= %d\n", it, current, lambda, qmax, lin_total);
+        if (qmax == o.max_trials || rho == 0 || !std::isfinite(lambda)) {
+            sum.termination = SOSLAM_PG_TERM_TRIALS;
+            it++;
+            break;
+        }
+    }
+    sum.iterations = it;
+    sum.final_chi2 = current;
+    sum.solve_seconds = now_sec() - t0;
+    if (out) *out = sum;
+    return SOSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void soslam_pg_options_default(soslam_pg_options* o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->max_iterations = 10;
+    o->max_trials = 10;
+    o->huber_delta = 1.0;
+    o->tau = 1e-5;
+    o->pcg_tolerance = 1e-10;
+    o->pcg_max_iterations = 4000;
+    o->verbose = 0;
+    o->device = -1;
+    o->stream = nullptr;
+}
+
+int soslam_pg_create(const soslam_pg_options* opts, soslam_pg** out)
+{
+    if (!out) return SOSLAM_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        set_last_error("no HIP device visible: the pose-graph backend has no CPU fallback");
+        return SOSLAM_ERR_NO_DEVICE;
+    }
+    std::unique_ptr<soslam_pg> h(new soslam_pg());
+    if (opts) h->opt = *opts; else soslam_pg_options_default(&h->opt);
+    if (h->opt.device >= 0) {
+        if (h->opt.device >= n_dev) { set_last_error("device %d out of range (%d visible)", h->opt.device, n_dev); return SOSLAM_ERR_INVALID_ARGUMENT; }
+        SOSLAM_HIP_CHECK(hipSetDevice(h->opt.device));
+    }
+    SOSLAM_HIP_CHECK(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    SOSLAM_HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_last_error("device %d is %s; this library carries gfx950 code objects only", h->device, prop.gcnArchName);
+        return SOSLAM_ERR_NO_DEVICE;
+    }
+    if (h->opt.stream) h->stream = static_cast<hipStream_t>(h->opt.stream);
+    else { SOSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    SOSLAM_HIP_CHECK(hipEventCreate(&h->ev[0]));
+    SOSLAM_HIP_CHECK(hipEventCreate(&h->ev[1]));
+    *out = h.release();
+    return SOSLAM_OK;
+}
+
+void soslam_pg_destroy(soslam_pg* h)
+{
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+int soslam_pg_set_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_t* fixed, uint32_t n_edge,
+                        const uint32_t* e_from, const uint32_t* e_to, const double* meas, const double* info36)
+{
+    if (!h || !n_vertex || !est || !info36 || (n_edge && (!e_from || !e_to || !meas))) return SOSLAM_ERR_INVALID_ARGUMENT;
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    h->have_graph = false;
+    return build_graph(h, n_vertex, est, fixed, n_edge, e_from, e_to, meas, info36);
+}
+
+int soslam_pg_optimize(soslam_pg* h, soslam_pg_summary* summary)
+{
+    if (!h) return SOSLAM_ERR_INVALID_ARGUMENT;
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    return run(h, summary);
+}
+
+int soslam_pg_get_estimates(soslam_pg* h, double* est)
+{
+    if (!h || !est) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_graph) { set_last_error("get_estimates before set_graph"); return SOSLAM_ERR_STATE; }
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    SOSLAM_HIP_CHECK(hipMemcpyAsync(est, h->est[h->cur].p, sizeof(double) * 7 * h->n_vertex, hipMemcpyDeviceToHost, h->stream));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return SOSLAM_OK;
+}
+
+int soslam_pg_get_iteration_log(soslam_pg* h, soslam_pg_iteration* out, int32_t capacity, int32_t* count)
+{
+    if (!h || !count) return SOSLAM_ERR_INVALID_ARGUMENT;
+    *count = (int32_t)h->log.size();
+    if (out) for (int32_t i = 0; i < capacity && i < *count; i++) out[i] = h->log[(size_t)i];
+    return SOSLAM_OK;
+}
+
+int soslam_pg_solve(const soslam_pg_options* opts, uint32_t n_vertex, double* est, const uint8_t* fixed, uint32_t n_edge,
+                    const uint32_t* e_from, const uint32_t* e_to, const double* meas, const double* info36,
+                    soslam_pg_summary* summary)
+{
+    soslam_pg* h = nullptr;
+    SOSLAM_CHECK(soslam_pg_create(opts, &h));
+    int st = soslam_pg_set_graph(h, n_vertex, est, fixed, n_edge, e_from, e_to, meas, info36);
+    if (st == SOSLAM_OK) st = soslam_pg_optimize(h, summary);
+    if (st == SOSLAM_OK) st = soslam_pg_get_estimates(h, est);
+    soslam_pg_destroy(h);
+    return st;
+}
+
+int soslam_pg_debug_linearize(soslam_pg* h, double* edge_e, double* edge_ji, double* edge_jj, double* chi2, double* h_dense,
+                              double* b)
+{
+    if (!h) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_graph) { set_last_error("debug_linearize before set_graph"); return SOSLAM_ERR_STATE; }
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    DevBuf<double> de, dji, djj;
+    const bool want_edges = edge_e || edge_ji || edge_jj;
+    if (want_edges) {
+        SOSLAM_CHECK(de.alloc((size_t)h->n_edge * 6));
+        SOSLAM_CHECK(dji.alloc((size_t)h->n_edge * 36));
+        SOSLAM_CHECK(djj.alloc((size_t)h->n_edge * 36));
+    }
+    SOSLAM_CHECK(linearize(h, want_edges ? de.p : nullptr, want_edges ? dji.p : nullptr, want_edges ? djj.p : nullptr));
+    double sc[2];
+    SOSLAM_CHECK(read_scal(h, sc, 2));
+    if (chi2) *chi2 = sc[0];
+    if (edge_e) SOSLAM_HIP_CHECK(hipMemcpy(edge_e, de.p, sizeof(double) * 6 * h->n_edge, hipMemcpyDeviceToHost));
+    if (edge_ji) SOSLAM_HIP_CHECK(hipMemcpy(edge_ji, dji.p, sizeof(double) * 36 * h->n_edge, hipMemcpyDeviceToHost));
+    if (edge_jj) SOSLAM_HIP_CHECK(hipMemcpy(edge_jj, djj.p, sizeof(double) * 36 * h->n_edge, hipMemcpyDeviceToHost));
+    if (b) SOSLAM_HIP_CHECK(hipMemcpy(b, h->b.p, sizeof(double) * 6 * h->n_free, hipMemcpyDeviceToHost));
+    if (h_dense) {
+        const size_t n6 = (size_t)h->n_free * 6;
+        std::vector<double> blk((size_t)h->n_blocks * 36);
+        SOSLAM_HIP_CHECK(hipMemcpy(blk.data(), h->H.p, sizeof(double) * blk.size(), hipMemcpyDeviceToHost));
+        std::memset(h_dense, 0, sizeof(double) * n6 * n6);
+        for (uint32_t k = 0; k < h->n_blocks; k++)
+            for (int a = 0; a < 6; a++)
+                for (int c = 0; c < 6; c++) {
+                    const size_t i = 6 * (size_t)h->h_blk_row[k] + a, j = 6 * (size_t)h->h_blk_col[k] + c;
+                    h_dense[i * n6 + j] = blk[36 * (size_t)k + a * 6 + c];
+                    h_dense[j * n6 + i] = blk[36 * (size_t)k + a * 6 + c];
+                }
+    }
+    (void)s;
+    return SOSLAM_OK;
+}
+
+int soslam_pg_time_linearize(soslam_pg* h, int32_t reps, float* avg_ms)
+{
+    if (!h || reps < 1 || !avg_ms) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_graph) { set_last_error("time_linearize before set_graph"); return SOSLAM_ERR_STATE; }
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    auto once = [&]() {
+        launch_pg_linearize(s, h->n_edge, h->est[h->cur].p, h->ef.p, h->et.p, h->meas.p, h->info, h->opt.huber_delta, h->eb.p, h->H.p,
+                            h->b.p, h->chi_part_lin.p, nullptr, nullptr, nullptr);
+    };
+    once();
+    SOSLAM_HIP_CHECK(hipEventRecord(h->ev[0], s));
+    for (int i = 0; i < reps; i++) once();
+    SOSLAM_HIP_CHECK(hipEventRecord(h->ev[1], s));
+    *avg_ms = elapsed_ms(h) / (float)reps;
+    SOSLAM_HIP_CHECK(hipGetLastError());
+    return SOSLAM_OK;
+}
+
+}  // extern "C"

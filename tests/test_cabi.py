@@ -25,8 +25,8 @@ def test_every_declared_symbol_is_exported(soslam, header):
 
 
 def test_binding_lists_cover_the_headers(soslam):
-    declared = set(_declared("soslam_ba.h")) | set(_declared("soslam_synth.h"))
-    assert declared <= set(soslam.BA_SYMBOLS + soslam.SYNTH_SYMBOLS) | set(getattr(soslam, "PG_SYMBOLS", []))
+    declared = set(_declared("soslam_ba.h")) | set(_declared("soslam_synth.h")) | set(_declared("soslam_pg.h"))
+    assert declared == set(soslam.BA_SYMBOLS + soslam.SYNTH_SYMBOLS + soslam.PG_SYMBOLS)
 
 
 def test_default_options_are_the_reference_configuration(soslam):

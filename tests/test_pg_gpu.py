@@ -1,0 +1,131 @@
+"""GPU parity tests of the pose-graph path (BASELINE.json configs[4]) against the CPU oracle and golden vectors."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(soslam):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no fallback")
+    from stereo_orb_slam_amd import pg, synth
+    return pg, synth, soslam
+
+
+def _oracle_solve(oracle_lib, g, iters=10):
+    L = oracle_lib.lib()
+    o = oracle_lib.PgOptions()
+    L.oracle_pg_options_default(C.byref(o))
+    o.max_iterations = iters
+    est = g.est.copy()
+    s = oracle_lib.PgSummary()
+    log = (oracle_lib.PgIteration * iters)()
+    rc = L.oracle_pg_solve(len(est), len(g.e_from), est, g.fixed, g.e_from, g.e_to, np.ascontiguousarray(g.meas),
+                           np.ascontiguousarray(g.info), C.byref(o), C.byref(s), C.cast(log, C.c_void_p))
+    assert rc == 0
+    return est, s, list(log)[: s.iterations]
+
+
+def test_edge_blocks_match_autograd_golden(gpu, golden_dir):
+    pg, synth, L = gpu
+    g = np.load(os.path.join(golden_dir, "pg_edge_jacobian.npz"))
+    n = len(g["e"])
+    est = np.concatenate([g["xi"], g["xj"]])                       # vertex k and n + k form edge k
+    ef, et = np.arange(n, dtype=np.uint32), np.arange(n, 2 * n, dtype=np.uint32)
+    with pg.PoseGraph() as h:
+        h.set_graph(est, np.zeros(2 * n, np.uint8), ef, et, g["z"], np.eye(6).reshape(36))
+        out = h.debug_linearize(dense=False)
+    np.testing.assert_allclose(out["e"], g["e"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(out["ji"], g["ji"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(out["jj"], g["jj"], rtol=1e-9, atol=1e-11)
+
+
+def test_linearized_system_matches_oracle(gpu, oracle_lib):
+    pg, synth, L = gpu
+    g = synth.generate_pg(6)
+    n6 = 6 * (len(g.est) - 1)
+    H, b = np.zeros((n6, n6)), np.zeros(n6)
+    chi = oracle_lib.lib().oracle_pg_linearize(len(g.est), len(g.e_from), np.ascontiguousarray(g.est), g.fixed, g.e_from, g.e_to,
+                                               np.ascontiguousarray(g.meas), np.ascontiguousarray(g.info), 1.0, H, b)
+    with pg.PoseGraph() as h:
+        h.load(g)
+        out = h.debug_linearize()
+    assert out["chi2"] == pytest.approx(chi, rel=1e-11)
+    np.testing.assert_allclose(out["H"], H, rtol=1e-9, atol=1e-11 * np.abs(H).max())
+    np.testing.assert_allclose(out["b"], b, rtol=1e-9, atol=1e-11 * np.abs(b).max())
+
+
+def _same_rotation(qa, qb, atol):
+    sign = np.sign((qa * qb).sum(1))[:, None]
+    np.testing.assert_allclose(qa * sign, qb, atol=atol)
+
+
+def test_solve_small_graph_matches_oracle(gpu, oracle_lib):
+    pg, synth, L = gpu
+    g = synth.generate_pg(6)
+    oest, osum, olog = _oracle_solve(oracle_lib, g)
+    with pg.PoseGraph() as h:
+        h.load(g)
+        s = h.optimize()
+        est, log = h.estimates(), h.iteration_log()
+    assert s.initial_chi2 == pytest.approx(osum.initial_chi2, rel=1e-11)
+    assert s.final_chi2 == pytest.approx(osum.final_chi2, rel=1e-5)
+    assert s.iterations == osum.iterations and s.termination == osum.termination
+    assert [e.trials for e in log] == [e.trials for e in olog]
+    np.testing.assert_allclose([e.chi2 for e in log], [e.chi2 for e in olog], rtol=1e-5)
+    np.testing.assert_allclose(est[:, :3], oest[:, :3], atol=1e-4)
+    _same_rotation(est[:, 3:], oest[:, 3:], 1e-5)
+    np.testing.assert_array_equal(est[0], g.est[0])               # vertex 0 fixed
+
+
+def test_solve_reaches_scipy_minimum(gpu, golden_dir):
+    pg, synth, L = gpu
+    g = np.load(os.path.join(golden_dir, "pg_minimum_scipy.npz"))
+    fixed = np.zeros(len(g["est0"]), np.uint8)
+    fixed[0] = 1
+    with pg.PoseGraph(pg.default_options(max_iterations=40)) as h:
+        h.set_graph(g["est0"], fixed, g["e_from"], g["e_to"], g["meas"], g["info"])
+        s = h.optimize()
+    assert s.initial_chi2 == pytest.approx(float(g["chi2_0"]), rel=1e-10)
+    assert s.final_chi2 == pytest.approx(float(g["chi2"]), rel=1e-6)
+
+
+def test_config5_full_size_matches_oracle(gpu, oracle_lib):
+    """BASELINE.json configs[4]: 5 000 SE(3) nodes / 20 000 edges, 5 Levenberg iterations against the oracle
+    (whose linear solve is PCG at 1e-12), plus monotone chi2."""
+    pg, synth, L = gpu
+    g = synth.generate_pg(5)
+    assert (len(g.est), len(g.e_from)) == (5000, 20000)
+    oest, osum, olog = _oracle_solve(oracle_lib, g, iters=5)
+    with pg.PoseGraph(pg.default_options(max_iterations=5)) as h:
+        h.load(g)
+        s = h.optimize()
+        est, log = h.estimates(), h.iteration_log()
+    assert s.final_chi2 == pytest.approx(osum.final_chi2, rel=1e-5)
+    chis = [e.chi2 for e in log]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip([s.initial_chi2] + chis, chis))
+    np.testing.assert_allclose(est[:, :3], oest[:, :3], atol=1e-3)
+    _same_rotation(est[:, 3:], oest[:, 3:], 1e-4)
+
+
+def test_one_call_and_errors(gpu):
+    pg, synth, L = gpu
+    g = synth.generate_pg(6)
+    est = g.est.copy()
+    s = pg.PgSummary()
+    o = pg.default_options(max_iterations=3)
+    st = L.lib().soslam_pg_solve(C.byref(o), len(est), L.ptr(est), L.ptr(g.fixed), len(g.e_from), L.ptr(g.e_from), L.ptr(g.e_to),
+                                 L.ptr(np.ascontiguousarray(g.meas)), L.ptr(np.ascontiguousarray(g.info)), C.byref(s))
+    assert st == 0 and s.final_chi2 < s.initial_chi2 and not np.array_equal(est, g.est)
+    bad = g.e_to.copy()
+    bad[3] = len(est) + 5
+    est2 = g.est.copy()
+    st = L.lib().soslam_pg_solve(C.byref(o), len(est2), L.ptr(est2), L.ptr(g.fixed), len(g.e_from), L.ptr(g.e_from), L.ptr(bad),
+                                 L.ptr(np.ascontiguousarray(g.meas)), L.ptr(np.ascontiguousarray(g.info)), C.byref(s))
+    assert st == L.ERR_INVALID_ARGUMENT
+    np.testing.assert_array_equal(est2, g.est)
