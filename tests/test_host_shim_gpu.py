@@ -81,3 +81,71 @@ def test_slam_schedule_runs(demo, tmp_path):
     c0 = oracle.cost(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r)
     c1 = oracle.cost(p.obs_cam, p.obs_pt, p.obs_uv, q.poses_cw(), q.points_f64(), p.proj_l, p.proj_r)
     assert c1 < 0.5 * c0
+
+
+def _tq_to_mat(v):
+    from scipy.spatial.transform import Rotation
+    T = np.tile(np.eye(4), (len(v), 1, 1))
+    T[:, :3, :3] = Rotation.from_quat(v[:, 3:]).as_matrix()
+    T[:, :3, 3] = v[:, :3]
+    return T
+
+
+def _mat_to_tq(T):
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(T[:, :3, :3]).as_quat()
+    return np.concatenate([T[:, :3, 3], q], 1)
+
+
+def test_pose_graph_optimizer_matches_oracle(oracle_lib, tmp_path):
+    """PoseGraphOptimizer::Optimize() of the host shim (loop measurements supplied as data, trailing global BA
+    skipped) against the oracle on the same float32 graph."""
+    import ctypes as C
+    from stereo_orb_slam_amd import dump_io, synth
+    exe = os.path.join(HOST, "build", "pg_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    g = synth.generate_pg(6)
+    n = len(g.est)
+    T = _tq_to_mat(g.est).astype(np.float32)
+    prob = synth.BaProblem(T, np.zeros((0, 3), np.float32), np.zeros(0, np.uint32), np.zeros(0, np.uint32),
+                           np.zeros((0, 4), np.float32), np.zeros(12), np.zeros(12))
+    dump_io.write_dump(str(tmp_path / "in"), prob)
+    loops = [(int(g.e_to[k]), int(g.e_from[k]), _tq_to_mat(g.meas[k:k + 1])[0].astype(np.float32)) for k in range(n - 1, len(g.e_from))]
+    with open(tmp_path / "loops.txt", "w") as f:
+        for a, b, M in loops:
+            f.write(f"{a} {b} " + " ".join("%.9g" % x for x in M.reshape(-1)) + "\n")
+    os.makedirs(tmp_path / "out", exist_ok=True)
+    out = subprocess.run([exe, str(tmp_path / "in"), str(tmp_path / "out"), "--loops", str(tmp_path / "loops.txt"), "--skip-ba",
+                          "--quiet", "--graph", str(tmp_path / "graph.txt")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    m = re.search(r"RESULT status 0 initial (\S+) final (\S+) iterations (\d+)", out.stdout)
+    assert m
+    q = dump_io.read_dump(str(tmp_path / "out"), np.zeros(12), np.zeros(12))
+
+    # the same graph for the oracle: vertices and odometry measurements from the float32 matrices the shim saw
+    T64 = T.astype(np.float64)
+    est0 = _mat_to_tq(T64)
+    rel = np.linalg.inv(T64[:-1]) @ T64[1:]
+    ef = np.concatenate([np.arange(n - 1), [b for _, b, _ in loops]]).astype(np.uint32)
+    et = np.concatenate([np.arange(1, n), [a for a, _, _ in loops]]).astype(np.uint32)
+    meas = np.concatenate([_mat_to_tq(rel), _mat_to_tq(np.array([M for _, _, M in loops], np.float64))])
+    L = oracle_lib.lib()
+    o = oracle_lib.PgOptions()
+    L.oracle_pg_options_default(C.byref(o))
+    s = oracle_lib.PgSummary()
+    est = np.ascontiguousarray(est0)
+    fixed = np.zeros(n, np.uint8)
+    fixed[0] = 1
+    assert L.oracle_pg_solve(n, len(ef), est, fixed, ef, et, np.ascontiguousarray(meas), np.ascontiguousarray(g.info), C.byref(o),
+                             C.byref(s), None) == 0
+    assert float(m.group(1)) == pytest.approx(s.initial_chi2, rel=1e-3, abs=1e-9)
+    assert float(m.group(2)) == pytest.approx(s.final_chi2, rel=1e-3, abs=1e-9)
+    got = _mat_to_tq(q.poses_wc.astype(np.float64))
+    np.testing.assert_allclose(got[:, :3], est[:, :3], atol=2e-3)
+    sign = np.sign((got[:, 3:] * est[:, 3:]).sum(1))[:, None]
+    np.testing.assert_allclose(got[:, 3:] * sign, est[:, 3:], atol=1e-4)
+    # the saved graph file has the reference's SavePoseGraph layout: header, 7 numbers per vertex, 9 per edge
+    lines = open(tmp_path / "graph.txt").read().strip().split("\n")
+    nv, ne = map(int, lines[0].split())
+    assert (nv, ne) == (n, len(ef)) and len(lines[1].split()) == 7 and len(lines[1 + nv].split()) == 9
