@@ -62,9 +62,45 @@ __device__ __forceinline__ void pose_rotation(const double* __restrict__ cam, Po
     p.a = 0.0;
 }
 
-// numerically safe (th - sin th)/th^3 and (1 - cos th)/th^2 near zero are not needed: the Rodrigues branch
-// is only taken for th^2 > eps, where the direct formulas lose at most ~eps/th^2 relative accuracy in terms
-// that are themselves O(th) corrections; see tests/test_ba_kernels_gpu.py::test_small_angles.
+// Per-camera quantities every observation of that camera needs, computed once per linearisation by
+// ba_pose_prepare and read through scalar loads (one camera per workgroup => wave-uniform):
+//   R (9)  rotation of the branch taken;  M (9) = R Jr so that d(R x)/dw = -[R x]x M;  t (3);  small flag.
+constexpr int kPoseStride = 24;
+struct PosePre {
+    double R[9];
+    double M[9];
+    double t[3];
+    bool small;
+};
+
+__device__ __forceinline__ void pose_prepare(const double* __restrict__ cam, double* __restrict__ out)
+{
+    PoseRot p;
+    pose_rotation(cam, p);
+    const double wx = p.w[0], wy = p.w[1], wz = p.w[2], b = p.b, c = p.c;
+    double Jr[9];
+    Jr[0] = 1.0 - c * (wy * wy + wz * wz); Jr[1] = b * wz + c * wx * wy;         Jr[2] = -b * wy + c * wx * wz;
+    Jr[3] = -b * wz + c * wx * wy;         Jr[4] = 1.0 - c * (wx * wx + wz * wz); Jr[5] = b * wx + c * wy * wz;
+    Jr[6] = b * wy + c * wx * wz;          Jr[7] = -b * wx + c * wy * wz;        Jr[8] = 1.0 - c * (wx * wx + wy * wy);
+#pragma unroll
+    for (int i = 0; i < 9; i++) out[i] = p.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            out[9 + i * 3 + j] = p.R[i * 3] * Jr[j] + p.R[i * 3 + 1] * Jr[3 + j] + p.R[i * 3 + 2] * Jr[6 + j];
+    out[18] = cam[3]; out[19] = cam[4]; out[20] = cam[5];
+    out[21] = p.small ? 1.0 : 0.0;
+    out[22] = 0.0; out[23] = 0.0;
+}
+
+__device__ __forceinline__ void pose_load(const double* __restrict__ pre, PosePre& p)
+{
+#pragma unroll
+    for (int i = 0; i < 9; i++) { p.R[i] = pre[i]; p.M[i] = pre[9 + i]; }
+    p.t[0] = pre[18]; p.t[1] = pre[19]; p.t[2] = pre[20];
+    p.small = pre[21] != 0.0;
+}
 
 // u, v of one camera and the 2x3 derivative wrt the camera-frame point
 __device__ __forceinline__ void project_rows(const double* __restrict__ P, const double* p, double& u, double& v,
@@ -97,12 +133,11 @@ __device__ __forceinline__ void huber(double s, double delta, double& rho0, doub
 }
 
 // residual only; returns rho(|r|^2)
-__device__ __forceinline__ double residual_cost(const PoseRot& pr, const double* __restrict__ t,
-                                                const double* x, const float4 uv, const Proj& P, double delta)
+__device__ __forceinline__ double residual_cost(const PosePre& pr, const double* x, const float4 uv, const Proj& P, double delta)
 {
     double y[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) y[i] = pr.R[i * 3] * x[0] + pr.R[i * 3 + 1] * x[1] + pr.R[i * 3 + 2] * x[2] + t[i];
+    for (int i = 0; i < 3; i++) y[i] = pr.R[i * 3] * x[0] + pr.R[i * 3 + 1] * x[1] + pr.R[i * 3 + 2] * x[2] + pr.t[i];
     double ul, vl, ur, vr;
     project_rows(P.l, y, ul, vl, nullptr);
     project_rows(P.r, y, ur, vr, nullptr);
@@ -113,16 +148,15 @@ __device__ __forceinline__ double residual_cost(const PoseRot& pr, const double*
 }
 
 // corrected residual r[4], J_c[24] (4x6 row-major), J_p[12] (4x3 row-major); returns rho(|r|^2)
-__device__ __forceinline__ double residual_jacobian(const PoseRot& pr, const double* __restrict__ t,
-                                                    const double* x, const float4 uv, const Proj& P, double delta,
-                                                    bool cam_fixed, double* __restrict__ r, double* __restrict__ jc,
-                                                    double* __restrict__ jp)
+__device__ __forceinline__ double residual_jacobian(const PosePre& pr, const double* x, const float4 uv, const Proj& P,
+                                                    double delta, bool cam_fixed, double* __restrict__ r,
+                                                    double* __restrict__ jc, double* __restrict__ jp)
 {
     double yr[3], y[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         yr[i] = pr.R[i * 3] * x[0] + pr.R[i * 3 + 1] * x[1] + pr.R[i * 3 + 2] * x[2];
-        y[i] = yr[i] + t[i];
+        y[i] = yr[i] + pr.t[i];
     }
     double A[12], ul, vl, ur, vr;
     project_rows(P.l, y, ul, vl, A);
@@ -140,20 +174,8 @@ __device__ __forceinline__ double residual_jacobian(const PoseRot& pr, const dou
         D[3] = -x[2]; D[4] = 0.0;   D[5] = x[0];
         D[6] = x[1];  D[7] = -x[0]; D[8] = 0.0;
     } else {
-        // -R [x]x Jr = -[R x]x R Jr ; build M = R Jr = R - b R[w]x + c R[w]x^2, then D = -[yr]x M.
-        // R [w]x = [w]x R (w is the rotation axis direction), so M = (I - b [w]x + c [w]x^2) R... but keep
-        // the direct form: Jr first (3x3), then R*Jr.
-        const double wx = pr.w[0], wy = pr.w[1], wz = pr.w[2], b = pr.b, c = pr.c;
-        double Jr[9];
-        Jr[0] = 1.0 - c * (wy * wy + wz * wz); Jr[1] = b * wz + c * wx * wy;         Jr[2] = -b * wy + c * wx * wz;
-        Jr[3] = -b * wz + c * wx * wy;         Jr[4] = 1.0 - c * (wx * wx + wz * wz); Jr[5] = b * wx + c * wy * wz;
-        Jr[6] = b * wy + c * wx * wz;          Jr[7] = -b * wx + c * wy * wz;        Jr[8] = 1.0 - c * (wx * wx + wy * wy);
-        double M[9];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                M[i * 3 + j] = pr.R[i * 3] * Jr[j] + pr.R[i * 3 + 1] * Jr[3 + j] + pr.R[i * 3 + 2] * Jr[6 + j];
+        // -R [x]x Jr = -[R x]x (R Jr) = -[yr]x M with M = R Jr from ba_pose_prepare
+        const double* M = pr.M;
         // D = -[yr]x M : row i of [yr]x M = yr x M_col... ([a]x M)_ij = a_{i+1} M_{i+2,j} - a_{i+2} M_{i+1,j}
 #pragma unroll
         for (int j = 0; j < 3; j++) {

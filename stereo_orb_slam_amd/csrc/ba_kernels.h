@@ -10,7 +10,8 @@
 
 namespace soslam {
 
-constexpr int kTileObs = 256;        // observations per linearize/cost workgroup (one camera per tile)
+constexpr int kTileObs = 1024;       // observations per linearize/cost workgroup (one camera per tile)
+constexpr int kTileThreads = 256;    // lanes per tile: up to 4 observations each
 constexpr int kTileVals = 28;        // 21 (J_c^T J_c upper) + 6 (J_c^T r) + 1 (rho)
 constexpr int kJcRow = 24;           // f64 per observation in the J_c array (4x6 row-major, 192 B)
 constexpr int kJprRow = 16;          // f64 per observation in the [J_p | r] array (4x3 row-major + 4, 128 B)
@@ -50,12 +51,15 @@ struct LmDiag {     // what a kernel needs to rebuild the point damping
     double radius, lo, hi;
 };
 
+// campre[n_cam][kPoseStride]: per-camera rotation block consumed by launch_linearize / launch_cost
+void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, double* campre);
+
 void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
-                      const double* cams, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
+                      const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
                       double* jc, double* jpr, double* tile_part);
 
 void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
-                 const double* cams, const double* pts, const Proj& P, double delta, double* cost_part);
+                 const double* campre, const double* pts, const Proj& P, double delta, double* cost_part);
 
 // out[0] = scale * sum_{i<n} in[i*stride + offset], one workgroup, fixed order (bitwise reproducible)
 void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out);

@@ -36,62 +36,110 @@ __device__ __forceinline__ double point_lambda(double cdiag, double s, const LmD
     return fmin(fmax(s2 * cdiag, lm.lo), lm.hi) / (lm.radius * s2);
 }
 
+// per-camera rotation block (R, R*Jr, t, branch flag) - 24 f64 per camera, recomputed whenever poses change
+__global__ __launch_bounds__(64) void ba_pose_prepare_kernel(uint32_t n_cam, const double* __restrict__ cams,
+                                                             double* __restrict__ campre)
+{
+    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+    if (c < n_cam) pose_prepare(cams + 6 * (size_t)c, campre + kPoseStride * (size_t)c);
+}
+
 // ---------------------------------------------------------------------------------------------------
-// K1  ba_linearize: one workgroup per camera tile (<= 256 observations of ONE camera, so the pose is
-// workgroup-uniform and arrives through scalar loads).  Each lane evaluates one observation, writes its
-// corrected Jacobian rows, and the workgroup reduces J_c^T J_c / J_c^T r / rho with wave shuffles + LDS.
+// K1  ba_linearize: one workgroup (256 lanes) per camera tile of <= 1024 observations of ONE camera, so the
+// camera's rotation block is workgroup-uniform and arrives through scalar loads.  Each lane evaluates up
+// to 4 observations (strided by 256, coalesced), writes their corrected Jacobian rows, and keeps its share
+// of J_c^T J_c / J_c^T r / rho in registers; one wave-shuffle + LDS reduction per workgroup.
 // Algorithmic bytes per observation: 16 (uv) + 4 (point id) + 24 (point) in, 192 + 128 out = 364
 // (SURVEY.md section 8(d) counts 368 with the second index).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kTileObs) void ba_linearize_kernel(
+__global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
     const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
-    const double* __restrict__ cams, const double* __restrict__ pts, const int32_t* __restrict__ cam_free,
+    const double* __restrict__ campre, const double* __restrict__ pts, const int32_t* __restrict__ cam_free,
     const Proj P, const double delta, double* __restrict__ jc_out, double* __restrict__ jpr_out,
     double* __restrict__ tile_part)
 {
-    __shared__ double red[(kTileObs / kWave) * kTileVals];
+    // Row-per-lane stores would touch 64 different lines per instruction; instead each wave stages its 64 rows
+    // in LDS (rows padded to 26 / 18 doubles: conflict-free ds_write_b128) and writes them back out as whole
+    // 1-KiB pieces, 16 contiguous bytes per lane.
+    constexpr int kJcPad = 26, kJprPad = 18;
+    __shared__ double red[(kTileThreads / kWave) * kTileVals];
+    __shared__ __attribute__((aligned(16))) double stage[(kTileThreads / kWave) * kWave * kJcPad];
     const Tile t = tiles[blockIdx.x];
     const int tid = threadIdx.x;
+    const int wave = tid / kWave, lane = tid % kWave;
     const bool fixed = cam_free[t.cam] < 0;
-    const double* cam = cams + 6 * (size_t)t.cam;
-    PoseRot pr;
-    pose_rotation(cam, pr);
-    const double tr[3] = {cam[3], cam[4], cam[5]};
+    PosePre pr;
+    pose_load(campre + kPoseStride * (size_t)t.cam, pr);
+    double* wstage = stage + wave * kWave * kJcPad;
 
     double v[kTileVals];
 #pragma unroll
     for (int i = 0; i < kTileVals; i++) v[i] = 0.0;
 
-    if (tid < (int)t.count) {
-        const size_t k = (size_t)t.start + tid;
-        const float4 m = uv[k];
-        const uint32_t p = obs_pt[k];
-        const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+    for (uint32_t base = 0; base < t.count; base += kTileThreads) {
+        const uint32_t o = base + tid;
+        const bool act = o < t.count;
+        const uint32_t wave_first = base + wave * kWave;                     // first observation of this wave's 64 rows
+        const int n_rows = wave_first < t.count ? (int)min(t.count - wave_first, (uint32_t)kWave) : 0;
         double r[4], jc[24], jp[12];
-        v[27] = residual_jacobian(pr, tr, x, m, P, delta, fixed, r, jc, jp);
-
-        double2* jrow = reinterpret_cast<double2*>(jc_out + kJcRow * k);
+        if (act) {
+            const size_t k = (size_t)t.start + o;
+            const float4 m = uv[k];
+            const uint32_t p = obs_pt[k];
+            const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+            v[27] += residual_jacobian(pr, x, m, P, delta, fixed, r, jc, jp);
+            if (!fixed) {
+                int idx = 0;
 #pragma unroll
-        for (int i = 0; i < 12; i++) jrow[i] = make_double2(jc[2 * i], jc[2 * i + 1]);
-        double2* prow = reinterpret_cast<double2*>(jpr_out + kJprRow * k);
+                for (int a = 0; a < 6; a++)
 #pragma unroll
-        for (int i = 0; i < 6; i++) prow[i] = make_double2(jp[2 * i], jp[2 * i + 1]);
-        prow[6] = make_double2(r[0], r[1]);
-        prow[7] = make_double2(r[2], r[3]);
-
-        if (!fixed) {
-            int idx = 0;
+                    for (int b = a; b < 6; b++)
+                        v[idx++] += jc[a] * jc[b] + jc[6 + a] * jc[6 + b] + jc[12 + a] * jc[12 + b] + jc[18 + a] * jc[18 + b];
 #pragma unroll
-            for (int a = 0; a < 6; a++)
+                for (int a = 0; a < 6; a++)
+                    v[21 + a] += jc[a] * r[0] + jc[6 + a] * r[1] + jc[12 + a] * r[2] + jc[18 + a] * r[3];
+            }
+        }
+        if (n_rows > 0) {
+            const size_t row0 = (size_t)t.start + wave_first;
+            // J_c: 64 rows x 24 doubles
+            if (act) {
+                double2* w2 = reinterpret_cast<double2*>(wstage + lane * kJcPad);
 #pragma unroll
-                for (int b = a; b < 6; b++)
-                    v[idx++] = jc[a] * jc[b] + jc[6 + a] * jc[6 + b] + jc[12 + a] * jc[12 + b] + jc[18 + a] * jc[18 + b];
+                for (int i = 0; i < 12; i++) w2[i] = make_double2(jc[2 * i], jc[2 * i + 1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+                double2* g = reinterpret_cast<double2*>(jc_out + kJcRow * row0);
 #pragma unroll
-            for (int a = 0; a < 6; a++)
-                v[21 + a] = jc[a] * r[0] + jc[6 + a] * r[1] + jc[12 + a] * r[2] + jc[18 + a] * r[3];
+                for (int i = 0; i < 12; i++) {
+                    const int c = i * kWave + lane;           // 16-byte piece of the wave's 12-KiB block
+                    const int row = c / 12, col = (c % 12) * 2;
+                    if (row < n_rows) g[c] = *reinterpret_cast<const double2*>(wstage + row * kJcPad + col);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // [J_p | r]: 64 rows x 16 doubles
+            if (act) {
+                double2* w2 = reinterpret_cast<double2*>(wstage + lane * kJprPad);
+#pragma unroll
+                for (int i = 0; i < 6; i++) w2[i] = make_double2(jp[2 * i], jp[2 * i + 1]);
+                w2[6] = make_double2(r[0], r[1]);
+                w2[7] = make_double2(r[2], r[3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+                double2* g = reinterpret_cast<double2*>(jpr_out + kJprRow * row0);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int c = i * kWave + lane;
+                    const int row = c / 8, col = (c % 8) * 2;
+                    if (row < n_rows) g[c] = *reinterpret_cast<const double2*>(wstage + row * kJprPad + col);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    const int wave = tid / kWave, lane = tid % kWave;
 #pragma unroll
     for (int i = 0; i < kTileVals; i++) {
         const double sum = wave_sum(v[i]);
@@ -101,30 +149,28 @@ __global__ __launch_bounds__(kTileObs) void ba_linearize_kernel(
     if (tid < kTileVals) {
         double sum = 0.0;
 #pragma unroll
-        for (int w = 0; w < kTileObs / kWave; w++) sum += red[w * kTileVals + tid];
+        for (int w = 0; w < kTileThreads / kWave; w++) sum += red[w * kTileVals + tid];
         tile_part[(size_t)blockIdx.x * kTileVals + tid] = sum;
     }
 }
 
 // K2  ba_cost: residual + loss only, same tiling.  48 B per observation in, 8 B per tile out.
-__global__ __launch_bounds__(kTileObs) void ba_cost_kernel(
+__global__ __launch_bounds__(kTileThreads) void ba_cost_kernel(
     const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
-    const double* __restrict__ cams, const double* __restrict__ pts, const Proj P, const double delta,
+    const double* __restrict__ campre, const double* __restrict__ pts, const Proj P, const double delta,
     double* __restrict__ cost_part)
 {
-    __shared__ double red[kTileObs / kWave];
+    __shared__ double red[kTileThreads / kWave];
     const Tile t = tiles[blockIdx.x];
     const int tid = threadIdx.x;
-    const double* cam = cams + 6 * (size_t)t.cam;
-    PoseRot pr;
-    pose_rotation(cam, pr);
-    const double tr[3] = {cam[3], cam[4], cam[5]};
+    PosePre pr;
+    pose_load(campre + kPoseStride * (size_t)t.cam, pr);
     double rho = 0.0;
-    if (tid < (int)t.count) {
-        const size_t k = (size_t)t.start + tid;
+    for (uint32_t o = tid; o < t.count; o += kTileThreads) {
+        const size_t k = (size_t)t.start + o;
         const uint32_t p = obs_pt[k];
         const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
-        rho = residual_cost(pr, tr, x, uv[k], P, delta);
+        rho += residual_cost(pr, x, uv[k], P, delta);
     }
     const double sum = wave_sum(rho);
     if (tid % kWave == 0) red[tid / kWave] = sum;
@@ -132,7 +178,7 @@ __global__ __launch_bounds__(kTileObs) void ba_cost_kernel(
     if (tid == 0) {
         double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < kTileObs / kWave; w++) s += red[w];
+        for (int w = 0; w < kTileThreads / kWave; w++) s += red[w];
         cost_part[blockIdx.x] = s;
     }
 }
@@ -531,20 +577,26 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
 
 // ---- launch wrappers --------------------------------------------------------------------------------
 
+void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, double* campre)
+{
+    if (!n_cam) return;
+    hipLaunchKernelGGL(ba_pose_prepare_kernel, dim3((n_cam + 63) / 64), dim3(64), 0, s, n_cam, cams, campre);
+}
+
 void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
-                      const double* cams, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
+                      const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
                       double* jc, double* jpr, double* tile_part)
 {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(ba_linearize_kernel, dim3(n_tiles), dim3(kTileObs), 0, s, tiles, uv, obs_pt, cams, pts, cam_free, P,
+    hipLaunchKernelGGL(ba_linearize_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre, pts, cam_free, P,
                        delta, jc, jpr, tile_part);
 }
 
 void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
-                 const double* cams, const double* pts, const Proj& P, double delta, double* cost_part)
+                 const double* campre, const double* pts, const Proj& P, double delta, double* cost_part)
 {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(ba_cost_kernel, dim3(n_tiles), dim3(kTileObs), 0, s, tiles, uv, obs_pt, cams, pts, P, delta, cost_part);
+    hipLaunchKernelGGL(ba_cost_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre, pts, P, delta, cost_part);
 }
 
 void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out)

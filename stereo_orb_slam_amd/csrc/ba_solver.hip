@@ -83,7 +83,7 @@ struct soslam_ba {
     // state and work buffers
     DevBuf<double> cams[2], pts[2];
     int cur = 0;
-    DevBuf<double> jc, jpr, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
+    DevBuf<double> campre, jc, jpr, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
     DevBuf<double> lin_resid, lin_work, dense, band, bandT, band_dinv;
     DevBuf<double> reduce_own;          // library-owned reduce buffer
     double* reduce = nullptr;           // [S blocks | rhs | diagB | gc_red | tail(4)] [scalars(SC_COUNT)]
@@ -437,6 +437,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         SOSLAM_CHECK(h->cams[i].alloc((size_t)n_cam * 6));
         SOSLAM_CHECK(h->pts[i].alloc((size_t)n_pt * 3));
     }
+    SOSLAM_CHECK(h->campre.alloc((size_t)n_cam * kPoseStride));
     SOSLAM_CHECK(h->jc.alloc((size_t)n_obs * kJcRow));
     SOSLAM_CHECK(h->jpr.alloc((size_t)n_obs * kJprRow));
     SOSLAM_CHECK(h->tile_part.alloc((size_t)h->n_tiles * kTileVals));
@@ -494,7 +495,8 @@ int linearize(soslam_ba* h)
     hipStream_t s = h->stream;
     {
         StageScope sc(h, SOSLAM_STAGE_LINEARIZE);
-        launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->cams[h->cur].p, h->pts[h->cur].p, h->cam_free.p,
+        launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);
+        launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p,
                          h->proj, h->opt.huber_delta, h->jc.p, h->jpr.p, h->tile_part.p);
         launch_cam_reduce(s, h->n_cam, h->cam_tile_start.p, h->cam_free.p, h->tile_part.p, h->B.p, h->gc.p);
         launch_sum_strided(s, h->tile_part.p, h->n_tiles, kTileVals, 27, 0.5, h->scalp() + SC_COST_X);
@@ -581,7 +583,8 @@ int take_step(soslam_ba* h, double radius)
     }
     {
         StageScope sc(h, SOSLAM_STAGE_COST);
-        launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->cams[h->cur ^ 1].p, h->pts[h->cur ^ 1].p, h->proj,
+        launch_pose_prepare(s, h->n_cam, h->cams[h->cur ^ 1].p, h->campre.p);
+        launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur ^ 1].p, h->proj,
                     h->opt.huber_delta, h->cost_part.p);
         launch_sum_strided(s, h->cost_part.p, h->n_tiles, 1, 0, 0.5, h->scalp() + SC_CAND_COST);
     }
@@ -972,6 +975,7 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
     SOSLAM_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     if (!h->linearized) SOSLAM_CHECK(linearize(h));
+    launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);   // the last cost evaluation left the candidate's block there
     if (kernel == SOSLAM_KERNEL_SCHUR || kernel == SOSLAM_KERNEL_BACKSUB) {
         // these read the point scales; make sure they exist
         if (!h->scale_init) launch_point_scale(s, h->n_pt, h->C.p, h->opt.jacobi_scaling, h->sp.p);
@@ -983,11 +987,11 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
     auto once = [&]() {
         switch (kernel) {
         case SOSLAM_KERNEL_LINEARIZE:
-            launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->cams[h->cur].p, h->pts[h->cur].p, h->cam_free.p,
+            launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p,
                              h->proj, h->opt.huber_delta, h->jc.p, h->jpr.p, h->tile_part.p);
             break;
         case SOSLAM_KERNEL_COST:
-            launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->cams[h->cur].p, h->pts[h->cur].p, h->proj,
+            launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->proj,
                         h->opt.huber_delta, h->cost_part.p);
             break;
         case SOSLAM_KERNEL_POINT_REDUCE:
