@@ -69,19 +69,23 @@ void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
                        const double* tile_part, double* B /* [F][36] */, double* gc /* [F][6] */);
 
-void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs,
-                         const double* jpr, double* C /* [n_pt][6] */, double* gp /* [n_pt][3] */);
+void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const double* jpr,
+                         double* C /* [n_pt][6] */, double* gp /* [n_pt][3] */);
 
 void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacobi, double* sp);
 
+// chunk windows into per-chunk slabs (chunk_slab[c] = offset of chunk c, layout [pair][36] then [camera][6])
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
-                  const int32_t* chunk_blocks, const int32_t* chunk_cams, const uint32_t* pt_obs,
-                  const uint32_t* q_pt, const uint8_t* q_slot, const double* jc, const double* jpr,
-                  const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv,
-                  double* S, double* rhs, double* scal);
+                  const uint32_t* chunk_slab, const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* jc,
+                  const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* slab,
+                  double* scal);
 
-void launch_schur_finalize(hipStream_t s, uint32_t n_free, const double* B, const double* gc,
-                           const int32_t* diag_block, double* S, double* rhs, double* diagB, double* gc_red);
+// S = B - sum(slabs), rhs = -g_c + sum(slab rhs parts) through host-built contribution lists (fixed order);
+// exports diag(B) and g_c next to them for the all-reduce
+void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, const uint32_t* blk_ptr, const uint32_t* blk_off,
+                         const uint32_t* cam_ptr, const uint32_t* cam_off, const uint32_t* blk_row, const uint32_t* blk_col,
+                         const double* slab, const double* B, const double* gc, double* S, double* rhs, double* diagB,
+                         double* gc_red);
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,
                      LmDiag lm, const int32_t* diag_block, double* S, double* lc);
@@ -90,8 +94,8 @@ void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, c
                        const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid,
                        double* cams_out, double* dc_full, double* scal);
 
-void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs,
-                    const uint32_t* obs_cam, const double* jc, const double* jpr, const double* dc_full,
+void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
+                    const double* jc, const double* jpr, const double* dc_full,
                     const double* Cinv, const double* C, const double* gp, const double* sp, const double* pts,
                     LmDiag lm, double bound_lo, double bound_hi, double* pts_out, double* dp, double* part);
 

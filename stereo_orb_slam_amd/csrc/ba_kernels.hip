@@ -3,8 +3,9 @@
 // Data layout in HBM:
 //   uv      [n_obs] float4          camera-major observation order (bucketed by camera)
 //   obs_pt  [n_obs] u32             internal point id (points sorted by first camera)
-//   jc      [n_obs][24] f64         loss-corrected 4x6 pose Jacobian, 192-B rows
-//   jpr     [n_obs][16] f64         loss-corrected 4x3 point Jacobian + 4 residuals, 128-B rows
+//   jc      [n_obs][24] f64         loss-corrected 4x6 pose Jacobian, 192-B rows, camera-major like uv
+//   jpr     [n_obs][16] f64         loss-corrected 4x3 point Jacobian + 4 residuals, 128-B rows, camera-major
+//                                   (point-major passes gather whole rows through the pt_obs index)
 //   C/gp    [n_pt][6] / [n_pt][3]   per-point J_p^T J_p (xx xy xz yy yz zz) and J_p^T r
 //   S       [n_blocks][36]          upper block-sparse reduced camera matrix (6x6 row-major blocks)
 // Every kernel is HBM-bound streaming / gather work at ~2 flop/B; nothing here is GEMM-shaped.
@@ -287,78 +288,151 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_scale_kernel(uint32_t n_
 
 // ---------------------------------------------------------------------------------------------------
 // K5  ba_schur: one workgroup per chunk of consecutive points whose cameras fit a window of KMAX local
-// slots.  Per batch (<= 128 observations) the first lanes form W = J_c^T J_p, invert the damped point
-// block in registers and stage W, Y = W Cinv in LDS; then every lane owns a fixed half (3x6) of one
-// local camera-pair block and accumulates Y_a W_b^T over the batch's points in REGISTERS (no atomics,
-// fixed order).  One flush per chunk adds the window into the global block-sparse S with f64 atomics.
+// slots.  Per batch (<= 128 observations):
+//   * all lanes fetch the batch's Jacobian rows from HBM as 16-byte pieces - one batch AHEAD, into
+//     registers, so the gather latency hides behind the previous batch's accumulation - and park them in LDS;
+//   * one lane per observation forms W = J_c^T J_p, inverts the damped point block in registers and writes
+//     W, Y = W Cinv to LDS;
+//   * every lane owns a fixed half (3x6) of one local camera-pair block and accumulates Y_a W_b^T over its
+//     share of the batch's points in REGISTERS (no atomics, fixed order).  When the chunk's window needs fewer
+//     lanes than the workgroup has, G lane groups share the items and split the points.
+// The chunk's window goes to its own slab with plain coalesced stores; ba_schur_reduce sums the slabs per
+// block in a fixed order, so the reduced camera system is bitwise reproducible.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kRawRow = 36;                       // J_c (24) + J_p (12) doubles staged per observation
+constexpr int kRawPieces = kRawRow / 2;           // 16-byte pieces per row
+
 template <int KMAX, int NT>
 __global__ __launch_bounds__(NT) void ba_schur_kernel(
-    const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches,
-    const int32_t* __restrict__ chunk_blocks, const int32_t* __restrict__ chunk_cams,
-    const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_pt, const uint8_t* __restrict__ q_slot,
-    const double* __restrict__ jc, const double* __restrict__ jpr, const double* __restrict__ C,
-    const double* __restrict__ gp, const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv,
-    double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ scal)
+    const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches, const uint32_t* __restrict__ chunk_slab,
+    const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_pt, const uint8_t* __restrict__ q_slot, const double* __restrict__ jc,
+    const double* __restrict__ jpr, const double* __restrict__ C, const double* __restrict__ gp,
+    const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv, double* __restrict__ slab,
+    double* __restrict__ scal)
 {
     constexpr int NPAIR = KMAX * (KMAX + 1) / 2;
-    constexpr int NITEM = 2 * NPAIR + KMAX;
-    constexpr int IPT = (NITEM + NT - 1) / NT;
-    static_assert(NT >= kBatchObs, "staging needs one lane per batch observation");
-    __shared__ double Wl[kBatchObs * 18];
-    __shared__ double Yl[kBatchObs * 18];
-    __shared__ double gl[kBatchObs * 3];
+    constexpr int MAX_IPT = (2 * NPAIR + KMAX + NT - 1) / NT;
+    constexpr int PPT = (kBatchObs * kRawPieces + NT - 1) / NT;   // raw pieces per lane
+    static_assert(NT >= kBatchObs && NT >= kBatchPts, "staging needs one lane per batch observation / point");
+    __shared__ __attribute__((aligned(16))) double raw[kBatchObs * kRawRow];
+    __shared__ __attribute__((aligned(16))) double WY[2 * kBatchObs * 18];   // W blocks, then Y blocks; later the exchange buffer
+    __shared__ double cil[kBatchPts * 6];     // inverse of the damped point blocks of the batch
+    __shared__ double gl[kBatchPts * 3];      // J_p^T r of the batch's points
     __shared__ uint8_t tab[kBatchPts * KMAX];
+    double* const Wl = WY;
+    double* const Yl = WY + kBatchObs * 18;
 
     const SchurChunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x;
+    const int K = (int)ch.n_local;
+    const int n_pair = K * (K + 1) / 2, n_items = 2 * n_pair + K;
+    const int IPT = (n_items + NT - 1) / NT;                                  // > 1 only for wide windows
+    const int G = (IPT == 1 && n_items <= 2 * kBatchObs) ? max(1, min(NT / max(n_items, 1), 4)) : 1;
+    const int grp = IPT == 1 ? tid / max(n_items, 1) : 0;
 
-    // item decode: kind 0/1 = rows 0-2 / 3-5 of pair (a,b); 2 = rhs of local camera a; 3 = idle
-    int ia[IPT], ib[IPT], kind[IPT], pair_id[IPT];
-    double acc[IPT][18];
+    int ia[MAX_IPT], ib[MAX_IPT], kind[MAX_IPT], slot_off[MAX_IPT];
+    double acc[MAX_IPT][18];
 #pragma unroll
-    for (int j = 0; j < IPT; j++) {
-        const int it = tid + j * NT;
-        ia[j] = 0; ib[j] = 0; kind[j] = 3; pair_id[j] = 0;
-        if (it < 2 * NPAIR) {
+    for (int j = 0; j < MAX_IPT; j++) {
+        const int it = IPT == 1 ? tid % max(n_items, 1) : tid + j * NT;
+        ia[j] = 0; ib[j] = 0; kind[j] = 3; slot_off[j] = 0;
+        const bool live = (IPT == 1) ? (j == 0 && grp < G) : (it < n_items);
+        if (live && it < 2 * n_pair) {
             int pair = it >> 1, a = 0;
-            pair_id[j] = pair;
-            while (pair >= KMAX - a) { pair -= KMAX - a; a++; }
+            const int pidx = pair;
+            while (pair >= K - a) { pair -= K - a; a++; }
             ia[j] = a; ib[j] = a + pair;
-            kind[j] = ((uint32_t)ib[j] < ch.n_local) ? (it & 1) : 3;
-        } else if (it < NITEM) {
-            ia[j] = it - 2 * NPAIR;
-            kind[j] = ((uint32_t)ia[j] < ch.n_local) ? 2 : 3;
+            kind[j] = it & 1;
+            slot_off[j] = pidx * 36 + (it & 1) * 18;            // position in the chunk's slab: pairs, then rhs
+        } else if (live && it < n_items) {
+            ia[j] = it - 2 * n_pair;
+            kind[j] = 2;
+            slot_off[j] = n_pair * 36 + ia[j] * 6;
         }
 #pragma unroll
         for (int i = 0; i < 18; i++) acc[j][i] = 0.0;
     }
 
+    // Prefetch registers, one batch ahead: this lane's 16-byte pieces of the batch's (contiguous, point-major)
+    // Jacobian rows; its observation's point id and window slot; and - one lane per point - the point's
+    // J_p^T J_p, Jacobi scale and J_p^T r.
+    double2 pre[PPT];
+    uint32_t pre_row[PPT];     // camera-major row of each piece's observation, fetched TWO batches ahead
+    uint32_t pre_pt = 0;
+    uint8_t pre_slot = 255;
+    double pre_c[6], pre_s[3], pre_g[3];
+    auto fetch_index = [&](uint32_t bi) {
+        const SchurBatch bt = batches[bi];
+        const int nq = (int)(bt.q_end - bt.q_begin);
+#pragma unroll
+        for (int s = 0; s < PPT; s++) {
+            const int o = (tid + s * NT) / kRawPieces;
+            pre_row[s] = o < nq ? pt_obs[bt.q_begin + o] : 0u;
+        }
+    };
+    auto fetch = [&](uint32_t bi) {   // rows of batch bi through the indices fetch_index(bi) loaded earlier
+        const SchurBatch bt = batches[bi];
+        const int nq = (int)(bt.q_end - bt.q_begin), np = (int)(bt.p_end - bt.p_begin);
+#pragma unroll
+        for (int s = 0; s < PPT; s++) {
+            const int piece = tid + s * NT, o = piece / kRawPieces, part = piece % kRawPieces;
+            pre[s] = make_double2(0.0, 0.0);
+            if (o < nq) {
+                const size_t q = pre_row[s];
+                pre[s] = part < 12 ? reinterpret_cast<const double2*>(jc + kJcRow * q)[part]
+                                   : reinterpret_cast<const double2*>(jpr + kJprRow * q)[part - 12];
+            }
+        }
+        if (tid < nq) { pre_pt = q_pt[bt.q_begin + tid]; pre_slot = q_slot[bt.q_begin + tid]; }
+        if (tid < np) {
+            const size_t p = (size_t)bt.p_begin + tid;
+#pragma unroll
+            for (int i = 0; i < 6; i++) pre_c[i] = C[6 * p + i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { pre_s[i] = sp[3 * p + i]; pre_g[i] = gp[3 * p + i]; }
+        }
+    };
+    if (ch.batch_begin < ch.batch_end) {
+        fetch_index(ch.batch_begin);
+        fetch(ch.batch_begin);
+        if (ch.batch_begin + 1 < ch.batch_end) fetch_index(ch.batch_begin + 1);
+    }
+
     for (uint32_t bi = ch.batch_begin; bi < ch.batch_end; bi++) {
         const SchurBatch bt = batches[bi];
         const int nq = (int)(bt.q_end - bt.q_begin), np = (int)(bt.p_end - bt.p_begin);
-        __syncthreads();
+        __syncthreads();   // previous batch's accumulation is done with the LDS images
+#pragma unroll
+        for (int s = 0; s < PPT; s++) {
+            const int piece = tid + s * NT;
+            if (piece < kBatchObs * kRawPieces) reinterpret_cast<double2*>(raw)[piece] = pre[s];
+        }
         for (int i = tid; i < np * KMAX; i += NT) tab[i] = 255;
+        if (tid < np) {
+            // one lane per point: damped 3x3 block inverted in registers
+            double m[6] = {pre_c[0], pre_c[1], pre_c[2], pre_c[3], pre_c[4], pre_c[5]}, ci[6];
+            m[0] += point_lambda(pre_c[0], pre_s[0], lm);
+            m[3] += point_lambda(pre_c[3], pre_s[1], lm);
+            m[5] += point_lambda(pre_c[5], pre_s[2], lm);
+            if (!sym3_inverse(m, ci)) scal[SC_SCHUR_STATUS] = 1.0;
+            double* o = Cinv + 6 * ((size_t)bt.p_begin + tid);
+#pragma unroll
+            for (int i = 0; i < 6; i++) { cil[tid * 6 + i] = ci[i]; o[i] = ci[i]; }
+            gl[tid * 3] = pre_g[0]; gl[tid * 3 + 1] = pre_g[1]; gl[tid * 3 + 2] = pre_g[2];
+        }
+        const uint32_t my_pt = pre_pt;
+        const uint8_t my_slot = pre_slot;
         __syncthreads();
         if (tid < nq) {
-            const uint32_t q = bt.q_begin + tid;
-            const size_t k = pt_obs[q];
-            const uint32_t p = q_pt[q];
-            const uint8_t slot = q_slot[q];
-            const double2* jcr = reinterpret_cast<const double2*>(jc + kJcRow * k);
-            const double2* jr = reinterpret_cast<const double2*>(jpr + kJprRow * k);
+            const int pl = (int)(my_pt - bt.p_begin);
+            const double2* row = reinterpret_cast<const double2*>(raw + tid * kRawRow);
             double a[24], b[12];
 #pragma unroll
-            for (int i = 0; i < 12; i++) { const double2 d = jcr[i]; a[2 * i] = d.x; a[2 * i + 1] = d.y; }
+            for (int i = 0; i < 12; i++) { const double2 d = row[i]; a[2 * i] = d.x; a[2 * i + 1] = d.y; }
 #pragma unroll
-            for (int i = 0; i < 6; i++) { const double2 d = jr[i]; b[2 * i] = d.x; b[2 * i + 1] = d.y; }
-            const double* Cp = C + 6 * (size_t)p;
-            const double* s3 = sp + 3 * (size_t)p;
-            double m[6] = {Cp[0], Cp[1], Cp[2], Cp[3], Cp[4], Cp[5]}, ci[6];
-            m[0] += point_lambda(Cp[0], s3[0], lm);
-            m[3] += point_lambda(Cp[3], s3[1], lm);
-            m[5] += point_lambda(Cp[5], s3[2], lm);
-            if (!sym3_inverse(m, ci)) scal[SC_SCHUR_STATUS] = 1.0;
+            for (int i = 0; i < 6; i++) { const double2 d = row[12 + i]; b[2 * i] = d.x; b[2 * i + 1] = d.y; }
+            const double* ci = cil + pl * 6;
+            const double c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3], c4 = ci[4], c5 = ci[5];
             double* Wt = Wl + tid * 18;
             double* Yt = Yl + tid * 18;
 #pragma unroll
@@ -367,23 +441,21 @@ __global__ __launch_bounds__(NT) void ba_schur_kernel(
                 const double w1 = a[r] * b[1] + a[6 + r] * b[4] + a[12 + r] * b[7] + a[18 + r] * b[10];
                 const double w2 = a[r] * b[2] + a[6 + r] * b[5] + a[12 + r] * b[8] + a[18 + r] * b[11];
                 Wt[r * 3] = w0; Wt[r * 3 + 1] = w1; Wt[r * 3 + 2] = w2;
-                Yt[r * 3] = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
-                Yt[r * 3 + 1] = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
-                Yt[r * 3 + 2] = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
+                Yt[r * 3] = w0 * c0 + w1 * c1 + w2 * c2;
+                Yt[r * 3 + 1] = w0 * c1 + w1 * c3 + w2 * c4;
+                Yt[r * 3 + 2] = w0 * c2 + w1 * c4 + w2 * c5;
             }
-            gl[tid * 3] = gp[3 * (size_t)p]; gl[tid * 3 + 1] = gp[3 * (size_t)p + 1]; gl[tid * 3 + 2] = gp[3 * (size_t)p + 2];
-            if (slot != 255) tab[(p - bt.p_begin) * KMAX + slot] = (uint8_t)tid;
-            if (tid == 0 || q_pt[q - 1] != p) {
-                double* o = Cinv + 6 * (size_t)p;
-#pragma unroll
-                for (int i = 0; i < 6; i++) o[i] = ci[i];
-            }
+            if (my_slot != 255) tab[pl * KMAX + my_slot] = (uint8_t)tid;
         }
         __syncthreads();
-        for (int pl = 0; pl < np; pl++) {
+        if (bi + 1 < ch.batch_end) {                 // in flight while this batch is accumulated
+            fetch(bi + 1);
+            if (bi + 2 < ch.batch_end) fetch_index(bi + 2);
+        }
+        for (int pl = grp; pl < np; pl += G) {
             const uint8_t* trow = tab + pl * KMAX;
 #pragma unroll
-            for (int j = 0; j < IPT; j++) {
+            for (int j = 0; j < MAX_IPT; j++) {
                 if (kind[j] < 2) {
                     const int ta = trow[ia[j]], tb = trow[ib[j]];
                     if (ta != 255 && tb != 255) {
@@ -399,7 +471,7 @@ __global__ __launch_bounds__(NT) void ba_schur_kernel(
                     const int ta = trow[ia[j]];
                     if (ta != 255) {
                         const double* Y = Yl + ta * 18;
-                        const double* g = gl + ta * 3;
+                        const double* g = gl + pl * 3;
 #pragma unroll
                         for (int r = 0; r < 6; r++) acc[j][r] += Y[r * 3] * g[0] + Y[r * 3 + 1] * g[1] + Y[r * 3 + 2] * g[2];
                     }
@@ -408,40 +480,66 @@ __global__ __launch_bounds__(NT) void ba_schur_kernel(
         }
     }
 
+    // combine the lane groups (fixed order: group 1, 2, 3 onto group 0) through the staging LDS
+    if (G > 1) {
+        for (int g = 1; g < G; g++) {
+            __syncthreads();
+            if (grp == g && kind[0] != 3) {
+                double* o = WY + (tid % n_items) * 18;     // n_items <= 2 * kBatchObs here
 #pragma unroll
-    for (int j = 0; j < IPT; j++) {
+                for (int i = 0; i < 18; i++) o[i] = acc[0][i];
+            }
+            __syncthreads();
+            if (grp == 0 && kind[0] != 3) {
+                const double* o = WY + tid * 18;
+#pragma unroll
+                for (int i = 0; i < 18; i++) acc[0][i] += o[i];
+            }
+        }
+    }
+    // the chunk's window: [pair][6x6] then [camera][6], contiguous => coalesced plain stores
+    double* out = slab + chunk_slab[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < MAX_IPT; j++) {
+        if (grp != 0) break;
         if (kind[j] < 2) {
-            const int32_t blk = chunk_blocks[(size_t)blockIdx.x * NPAIR + pair_id[j]];
-            if (blk >= 0) {
-                double* o = S + 36 * (size_t)blk + kind[j] * 18;
 #pragma unroll
-                for (int i = 0; i < 18; i++) unsafeAtomicAdd(o + i, -acc[j][i]);
-            }
+            for (int i = 0; i < 18; i++) out[slot_off[j] + i] = acc[j][i];
         } else if (kind[j] == 2) {
-            const int32_t f = chunk_cams[(size_t)blockIdx.x * KMAX + ia[j]];
-            if (f >= 0) {
 #pragma unroll
-                for (int r = 0; r < 6; r++) unsafeAtomicAdd(rhs + 6 * (size_t)f + r, acc[j][r]);
-            }
+            for (int r = 0; r < 6; r++) out[slot_off[j] + r] = acc[j][r];
         }
     }
 }
 
-// S_ff += B_f, rhs_f -= g_c,f (this rank's share), and export diag(B), g_c for the all-reduce
-__global__ __launch_bounds__(64) void ba_schur_finalize_kernel(uint32_t n_free, const double* __restrict__ B,
-                                                               const double* __restrict__ gc,
-                                                               const int32_t* __restrict__ diag_block,
-                                                               double* __restrict__ S, double* __restrict__ rhs,
-                                                               double* __restrict__ diagB, double* __restrict__ gc_red)
+// S = B (diagonal blocks) - sum of the chunk windows, rhs = -g_c + sum of the chunk rhs parts, in the fixed
+// order of the host-built contribution lists; also exports diag(B) and g_c for the all-reduce.  Overwrites
+// S and rhs completely (no memset needed).
+__global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, uint32_t n_free, const uint32_t* __restrict__ blk_ptr,
+                                                             const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ cam_ptr,
+                                                             const uint32_t* __restrict__ cam_off, const uint32_t* __restrict__ blk_row,
+                                                             const uint32_t* __restrict__ blk_col, const double* __restrict__ slab,
+                                                             const double* __restrict__ B, const double* __restrict__ gc,
+                                                             double* __restrict__ S, double* __restrict__ rhs,
+                                                             double* __restrict__ diagB, double* __restrict__ gc_red)
 {
-    const uint32_t f = blockIdx.x;
+    const uint32_t id = blockIdx.x;
     const int t = threadIdx.x;
-    if (f >= n_free) return;
-    if (t < 36) S[36 * (size_t)diag_block[f] + t] += B[36 * (size_t)f + t];
-    if (t < 6) {
-        rhs[6 * (size_t)f + t] -= gc[6 * (size_t)f + t];
+    if (id < n_blocks) {
+        if (t >= 36) return;
+        double s = 0.0;
+        for (uint32_t e = blk_ptr[id]; e < blk_ptr[id + 1]; e++) s += slab[blk_off[e] + t];
+        const uint32_t f = blk_row[id];
+        S[36 * (size_t)id + t] = (f == blk_col[id] ? B[36 * (size_t)f + t] : 0.0) - s;
+    } else {
+        const uint32_t f = id - n_blocks;
+        if (f >= n_free || t >= 6) return;
+        double s = 0.0;
+        for (uint32_t e = cam_ptr[f]; e < cam_ptr[f + 1]; e++) s += slab[cam_off[e] + t];
+        const double g = gc[6 * (size_t)f + t];
+        rhs[6 * (size_t)f + t] = s - g;
         diagB[6 * (size_t)f + t] = B[36 * (size_t)f + t * 7];
-        gc_red[6 * (size_t)f + t] = gc[6 * (size_t)f + t];
+        gc_red[6 * (size_t)f + t] = g;
     }
 }
 
@@ -514,7 +612,7 @@ __global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, cons
 // per-workgroup partials {model-cost share, |step|^2, |x|^2, g.step, max|g|}
 __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
     uint32_t n_pt, const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_obs,
-    const uint32_t* __restrict__ obs_cam, const double* __restrict__ jc, const double* __restrict__ jpr,
+    const uint32_t* __restrict__ q_cam, const double* __restrict__ jc, const double* __restrict__ jpr,
     const double* __restrict__ dc_full, const double* __restrict__ Cinv, const double* __restrict__ C,
     const double* __restrict__ gp, const double* __restrict__ sp, const double* __restrict__ pts, const LmDiag lm,
     const double bound_lo, const double bound_hi, double* __restrict__ pts_out, double* __restrict__ dp_out,
@@ -528,7 +626,7 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
         double t0 = g[0], t1 = g[1], t2 = g[2];
         for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
             const size_t k = pt_obs[q];
-            const double* d = dc_full + 6 * (size_t)obs_cam[k];
+            const double* d = dc_full + 6 * (size_t)q_cam[q];
             const double d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
             const double2* jcr = reinterpret_cast<const double2*>(jc + kJcRow * k);
             const double2* jr = reinterpret_cast<const double2*>(jpr + kJprRow * k);
@@ -588,8 +686,8 @@ void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const 
                       double* jc, double* jpr, double* tile_part)
 {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(ba_linearize_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre, pts, cam_free, P,
-                       delta, jc, jpr, tile_part);
+    hipLaunchKernelGGL(ba_linearize_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre, pts,
+                       cam_free, P, delta, jc, jpr, tile_part);
 }
 
 void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
@@ -616,8 +714,8 @@ void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_s
     hipLaunchKernelGGL(ba_cam_reduce_kernel, dim3(n_cam), dim3(64), 0, s, cam_tile_start, cam_free, tile_part, B, gc);
 }
 
-void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs,
-                         const double* jpr, double* C, double* gp)
+void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const double* jpr,
+                         double* C, double* gp)
 {
     if (!n_pt) return;
     hipLaunchKernelGGL(ba_point_reduce_kernel, dim3((n_pt + kPointBlock - 1) / kPointBlock), dim3(kPointBlock), 0, s, n_pt,
@@ -632,25 +730,27 @@ void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacob
 }
 
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
-                  const int32_t* chunk_blocks, const int32_t* chunk_cams, const uint32_t* pt_obs,
-                  const uint32_t* q_pt, const uint8_t* q_slot, const double* jc, const double* jpr,
-                  const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv,
-                  double* S, double* rhs, double* scal)
+                  const uint32_t* chunk_slab, const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* jc,
+                  const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* slab,
+                  double* scal)
 {
     if (!n_chunks) return;
     if (kmax <= 16)
-        hipLaunchKernelGGL((ba_schur_kernel<16, 320>), dim3(n_chunks), dim3(320), 0, s, chunks, batches, chunk_blocks,
-                           chunk_cams, pt_obs, q_pt, q_slot, jc, jpr, C, gp, sp, lm, Cinv, S, rhs, scal);
+        hipLaunchKernelGGL((ba_schur_kernel<16, 384>), dim3(n_chunks), dim3(384), 0, s, chunks, batches, chunk_slab, pt_obs, q_pt, q_slot,
+                           jc, jpr, C, gp, sp, lm, Cinv, slab, scal);
     else
-        hipLaunchKernelGGL((ba_schur_kernel<32, 576>), dim3(n_chunks), dim3(576), 0, s, chunks, batches, chunk_blocks,
-                           chunk_cams, pt_obs, q_pt, q_slot, jc, jpr, C, gp, sp, lm, Cinv, S, rhs, scal);
+        hipLaunchKernelGGL((ba_schur_kernel<32, 576>), dim3(n_chunks), dim3(576), 0, s, chunks, batches, chunk_slab, pt_obs, q_pt, q_slot,
+                           jc, jpr, C, gp, sp, lm, Cinv, slab, scal);
 }
 
-void launch_schur_finalize(hipStream_t s, uint32_t n_free, const double* B, const double* gc,
-                           const int32_t* diag_block, double* S, double* rhs, double* diagB, double* gc_red)
+void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, const uint32_t* blk_ptr, const uint32_t* blk_off,
+                         const uint32_t* cam_ptr, const uint32_t* cam_off, const uint32_t* blk_row, const uint32_t* blk_col,
+                         const double* slab, const double* B, const double* gc, double* S, double* rhs, double* diagB,
+                         double* gc_red)
 {
-    if (!n_free) return;
-    hipLaunchKernelGGL(ba_schur_finalize_kernel, dim3(n_free), dim3(64), 0, s, n_free, B, gc, diag_block, S, rhs, diagB, gc_red);
+    if (!(n_blocks + n_free)) return;
+    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(n_blocks + n_free), dim3(64), 0, s, n_blocks, n_free, blk_ptr, blk_off, cam_ptr,
+                       cam_off, blk_row, blk_col, slab, B, gc, S, rhs, diagB, gc_red);
 }
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,
@@ -669,14 +769,14 @@ void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, c
                        cams_out, dc_full, scal);
 }
 
-void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs,
-                    const uint32_t* obs_cam, const double* jc, const double* jpr, const double* dc_full,
+void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
+                    const double* jc, const double* jpr, const double* dc_full,
                     const double* Cinv, const double* C, const double* gp, const double* sp, const double* pts,
                     LmDiag lm, double bound_lo, double bound_hi, double* pts_out, double* dp, double* part)
 {
     if (!n_pt) return;
     hipLaunchKernelGGL(ba_backsub_kernel, dim3((n_pt + kPointBlock - 1) / kPointBlock), dim3(kPointBlock), 0, s, n_pt, pt_start,
-                       pt_obs, obs_cam, jc, jpr, dc_full, Cinv, C, gp, sp, pts, lm, bound_lo, bound_hi, pts_out, dp, part);
+                       pt_obs, q_cam, jc, jpr, dc_full, Cinv, C, gp, sp, pts, lm, bound_lo, bound_hi, pts_out, dp, part);
 }
 
 }  // namespace soslam

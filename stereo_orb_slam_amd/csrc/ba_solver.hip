@@ -72,10 +72,12 @@ struct soslam_ba {
 
     // static device data
     DevBuf<float4> uv;
-    DevBuf<uint32_t> obs_pt, obs_cam, cam_tile_start, pt_start, pt_obs, q_pt;
+    DevBuf<uint32_t> obs_pt, cam_tile_start, pt_start, pt_obs, q_pt, q_cam;
     DevBuf<uint8_t> q_slot, ent_trans;
     DevBuf<Tile> tiles;
-    DevBuf<int32_t> cam_free, chunk_blocks, chunk_cams, diag_block;
+    DevBuf<int32_t> cam_free, diag_block;
+    DevBuf<uint32_t> chunk_slab, blk_contrib_ptr, blk_contrib_off, cam_contrib_ptr, cam_contrib_off;
+    DevBuf<double> slab;
     DevBuf<SchurChunk> chunks;
     DevBuf<SchurBatch> batches;
     DevBuf<uint32_t> row_ptr, ent_col, ent_blk, blk_row, blk_col;
@@ -245,7 +247,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     h->n_tiles = (uint32_t)tiles.size();
 
     // point-major lists (camera ascending inside a point because the scan is camera-major)
-    std::vector<uint32_t> pt_start(n_pt + 1, 0), pt_obs(n_obs), q_pt(n_obs);
+    std::vector<uint32_t> pt_start(n_pt + 1, 0), pt_obs(n_obs), q_pt(n_obs), q_cam(n_obs);
     for (uint32_t i = 0; i < n_obs; i++) pt_start[v_obs_pt[i] + 1]++;
     for (uint32_t p = 0; p < n_pt; p++) pt_start[p + 1] += pt_start[p];
     {
@@ -254,6 +256,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             const uint32_t q = fill[v_obs_pt[i]]++;
             pt_obs[q] = i;
             q_pt[q] = v_obs_pt[i];
+            q_cam[q] = v_obs_cam[i];
         }
     }
 
@@ -331,11 +334,13 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     }
 
     // Schur chunks: consecutive points whose free cameras fit kmax local slots; batches of <= 128 obs
-    const int K = h->kmax, NPAIR = K * (K + 1) / 2;
+    const int K = h->kmax;
     const uint32_t chunk_pts_max = std::max<uint32_t>(32, std::min<uint32_t>(1024, n_pt / 512 + 1));
     std::vector<SchurChunk> chunks;
     std::vector<SchurBatch> batches;
-    std::vector<int32_t> chunk_blocks, chunk_cams;
+    std::vector<uint32_t> chunk_slab;                       // offset of each chunk's window in the slab
+    std::vector<std::vector<uint32_t>> blk_contrib(h->n_blocks), cam_contrib(nf);
+    uint64_t slab_count = 0;
     std::vector<uint8_t> q_slot(n_obs, 255);
     {
         std::vector<uint32_t> local, merged, fc;
@@ -362,15 +367,19 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                 if (f < 0) continue;
                 q_slot[q] = (uint8_t)(std::lower_bound(local.begin(), local.end(), (uint32_t)f) - local.begin());
             }
-            const size_t cb = chunk_blocks.size(), cc = chunk_cams.size();
-            chunk_blocks.resize(cb + NPAIR, -1);
-            chunk_cams.resize(cc + K, -1);
+            // slab layout of this chunk: [pair (a <= b < n_local)][36] then [camera a][6]; every pair whose block
+            // exists in the pattern (it always does: the pattern is a superset) feeds that block's list
+            const uint32_t base = (uint32_t)slab_count;
+            chunk_slab.push_back(base);
+            const int KL = (int)local.size();
             int pair = 0;
-            for (int a = 0; a < K; a++) {
-                if (a < (int)local.size()) chunk_cams[cc + a] = (int32_t)local[a];
-                for (int b = a; b < K; b++, pair++)
-                    if (b < (int)local.size()) chunk_blocks[cb + pair] = find_block(local[a], local[b]);
-            }
+            for (int a = 0; a < KL; a++)
+                for (int b = a; b < KL; b++, pair++) {
+                    const int32_t blk = find_block(local[a], local[b]);
+                    if (blk >= 0) blk_contrib[(size_t)blk].push_back(base + (uint32_t)pair * 36);
+                }
+            for (int a = 0; a < KL; a++) cam_contrib[local[a]].push_back(base + (uint32_t)pair * 36 + (uint32_t)a * 6);
+            slab_count += (uint64_t)pair * 36 + (uint64_t)KL * 6;
             chunks.push_back(ch);
             chunk_p0 = p_end;
             local.clear();
@@ -390,6 +399,16 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             local = merged;
         }
         close_chunk(n_pt);
+    }
+    if (slab_count > 0xFFFFFFF0ull) { set_last_error("Schur slab exceeds 32-bit offsets"); return SOSLAM_ERR_INVALID_ARGUMENT; }
+    std::vector<uint32_t> bc_ptr(h->n_blocks + 1, 0), bc_off, cc_ptr(nf + 1, 0), cc_off;
+    for (uint32_t b = 0; b < h->n_blocks; b++) {
+        bc_ptr[b + 1] = bc_ptr[b] + (uint32_t)blk_contrib[b].size();
+        bc_off.insert(bc_off.end(), blk_contrib[b].begin(), blk_contrib[b].end());
+    }
+    for (uint32_t f = 0; f < nf; f++) {
+        cc_ptr[f + 1] = cc_ptr[f] + (uint32_t)cam_contrib[f].size();
+        cc_off.insert(cc_off.end(), cam_contrib[f].begin(), cam_contrib[f].end());
     }
     h->n_chunks = (uint32_t)chunks.size();
     h->n_batches = (uint32_t)batches.size();
@@ -412,18 +431,22 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     // uploads
     SOSLAM_CHECK(h->uv.upload(uv, s));
     SOSLAM_CHECK(h->obs_pt.upload(v_obs_pt, s));
-    SOSLAM_CHECK(h->obs_cam.upload(v_obs_cam, s));
+    SOSLAM_CHECK(h->q_cam.upload(q_cam, s));
+    SOSLAM_CHECK(h->pt_obs.upload(pt_obs, s));
     SOSLAM_CHECK(h->tiles.upload(tiles, s));
     SOSLAM_CHECK(h->cam_tile_start.upload(cam_tile_start, s));
     SOSLAM_CHECK(h->cam_free.upload(h->h_cam_free, s));
     SOSLAM_CHECK(h->pt_start.upload(pt_start, s));
-    SOSLAM_CHECK(h->pt_obs.upload(pt_obs, s));
     SOSLAM_CHECK(h->q_pt.upload(q_pt, s));
     SOSLAM_CHECK(h->q_slot.upload(q_slot, s));
     SOSLAM_CHECK(h->chunks.upload(chunks, s));
     SOSLAM_CHECK(h->batches.upload(batches, s));
-    SOSLAM_CHECK(h->chunk_blocks.upload(chunk_blocks, s));
-    SOSLAM_CHECK(h->chunk_cams.upload(chunk_cams, s));
+    SOSLAM_CHECK(h->chunk_slab.upload(chunk_slab, s));
+    SOSLAM_CHECK(h->blk_contrib_ptr.upload(bc_ptr, s));
+    SOSLAM_CHECK(h->blk_contrib_off.upload(bc_off, s));
+    SOSLAM_CHECK(h->cam_contrib_ptr.upload(cc_ptr, s));
+    SOSLAM_CHECK(h->cam_contrib_off.upload(cc_off, s));
+    SOSLAM_CHECK(h->slab.alloc((size_t)slab_count));
     SOSLAM_CHECK(h->diag_block.upload(diag_block, s));
     SOSLAM_CHECK(h->row_ptr.upload(row_ptr, s));
     SOSLAM_CHECK(h->ent_col.upload(ent_col, s));
@@ -533,11 +556,11 @@ int take_step(soslam_ba* h, double radius)
     const LmDiag lm = lm_diag(h, radius);
     {
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
-        SOSLAM_HIP_CHECK(hipMemsetAsync(h->reduce, 0, sizeof(double) * h->reduce_main, s));
-        launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_blocks.p, h->chunk_cams.p, h->pt_obs.p,
-                     h->q_pt.p, h->q_slot.p, h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->S(), h->rhs(),
-                     h->scalp());
-        launch_schur_finalize(s, h->n_free, h->B.p, h->gc.p, h->diag_block.p, h->S(), h->rhs(), h->diagB(), h->gc_red());
+        launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->pt_obs.p, h->q_pt.p, h->q_slot.p,
+                     h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
+        launch_schur_reduce(s, h->n_blocks, h->n_free, h->blk_contrib_ptr.p, h->blk_contrib_off.p, h->cam_contrib_ptr.p,
+                            h->cam_contrib_off.p, h->blk_row.p, h->blk_col.p, h->slab.p, h->B.p, h->gc.p, h->S(), h->rhs(),
+                            h->diagB(), h->gc_red());
         SOSLAM_HIP_CHECK(hipMemcpyAsync(h->tail(), h->scalp() + SC_COST_X, sizeof(double), hipMemcpyDeviceToDevice, s));
     }
     {
@@ -576,7 +599,7 @@ int take_step(soslam_ba* h, double radius)
     }
     {
         StageScope sc(h, SOSLAM_STAGE_BACKSUB);
-        launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->obs_cam.p, h->jc.p, h->jpr.p, h->dc_full.p, h->Cinv.p, h->C.p,
+        launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->jc.p, h->jpr.p, h->dc_full.p, h->Cinv.p, h->C.p,
                        h->gp.p, h->sp.p, h->pts[h->cur].p, lm, h->opt.lower_bound, h->opt.upper_bound, h->pts[h->cur ^ 1].p,
                        h->dp.p, h->part.p);
         launch_sum5(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS);
@@ -998,12 +1021,11 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
             launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->jpr.p, h->C.p, h->gp.p);
             break;
         case SOSLAM_KERNEL_SCHUR:
-            launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_blocks.p, h->chunk_cams.p, h->pt_obs.p,
-                         h->q_pt.p, h->q_slot.p, h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->S(), h->rhs(),
-                         h->scalp());
+            launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->pt_obs.p, h->q_pt.p, h->q_slot.p,
+                         h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
             break;
         case SOSLAM_KERNEL_BACKSUB:
-            launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->obs_cam.p, h->jc.p, h->jpr.p, h->dc_full.p, h->Cinv.p,
+            launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->jc.p, h->jpr.p, h->dc_full.p, h->Cinv.p,
                            h->C.p, h->gp.p, h->sp.p, h->pts[h->cur].p, lm, h->opt.lower_bound, h->opt.upper_bound,
                            h->pts[h->cur ^ 1].p, h->dp.p, h->part.p);
             break;
@@ -1013,9 +1035,8 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
     if (kernel < 0 || kernel > SOSLAM_KERNEL_BACKSUB) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return SOSLAM_ERR_INVALID_ARGUMENT; }
     if (kernel == SOSLAM_KERNEL_BACKSUB) {
         SOSLAM_HIP_CHECK(hipMemsetAsync(h->dc_full.p, 0, sizeof(double) * 6 * h->n_cam, s));
-        SOSLAM_HIP_CHECK(hipMemsetAsync(h->reduce, 0, sizeof(double) * h->reduce_main, s));
-        launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_blocks.p, h->chunk_cams.p, h->pt_obs.p, h->q_pt.p,
-                     h->q_slot.p, h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->S(), h->rhs(), h->scalp());
+        launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->pt_obs.p, h->q_pt.p, h->q_slot.p,
+                     h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
     }
     once();  // warm-up
     SOSLAM_HIP_CHECK(hipEventRecord(e0, s));
