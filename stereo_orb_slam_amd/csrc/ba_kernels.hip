@@ -319,8 +319,10 @@ __global__ __launch_bounds__(NT) void ba_schur_kernel(
     __shared__ double cil[kBatchPts * 6];     // inverse of the damped point blocks of the batch
     __shared__ double gl[kBatchPts * 3];      // J_p^T r of the batch's points
     __shared__ uint8_t tab[kBatchPts * KMAX];
+    __shared__ uint8_t pt_l[kBatchObs];       // batch-local point of each staged observation
     double* const Wl = WY;
     double* const Yl = WY + kBatchObs * 18;
+    static_assert(NT >= 3 * kBatchObs, "W/Y staging uses three lanes per observation");
 
     const SchurChunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x;
@@ -422,30 +424,32 @@ __global__ __launch_bounds__(NT) void ba_schur_kernel(
         }
         const uint32_t my_pt = pre_pt;
         const uint8_t my_slot = pre_slot;
+        if (tid < nq) pt_l[tid] = (uint8_t)(my_pt - bt.p_begin);
         __syncthreads();
-        if (tid < nq) {
-            const int pl = (int)(my_pt - bt.p_begin);
-            const double2* row = reinterpret_cast<const double2*>(raw + tid * kRawRow);
-            double a[24], b[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) { const double2 d = row[i]; a[2 * i] = d.x; a[2 * i + 1] = d.y; }
-#pragma unroll
-            for (int i = 0; i < 6; i++) { const double2 d = row[12 + i]; b[2 * i] = d.x; b[2 * i + 1] = d.y; }
-            const double* ci = cil + pl * 6;
+        if (tid < nq && my_slot != 255) tab[(int)(my_pt - bt.p_begin) * KMAX + my_slot] = (uint8_t)tid;
+        // W = J_c^T J_p and Y = W Cinv: three lanes per observation, two of the six rows each
+        if (tid < 3 * nq) {
+            const int o = tid / 3, r0 = (tid % 3) * 2;
+            const double* row = raw + o * kRawRow;
+            const double* b = row + 24;
+            const double* ci = cil + (int)pt_l[o] * 6;
             const double c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3], c4 = ci[4], c5 = ci[5];
-            double* Wt = Wl + tid * 18;
-            double* Yt = Yl + tid * 18;
+            const double b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5], b6 = b[6], b7 = b[7], b8 = b[8],
+                         b9 = b[9], b10 = b[10], b11 = b[11];
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const double w0 = a[r] * b[0] + a[6 + r] * b[3] + a[12 + r] * b[6] + a[18 + r] * b[9];
-                const double w1 = a[r] * b[1] + a[6 + r] * b[4] + a[12 + r] * b[7] + a[18 + r] * b[10];
-                const double w2 = a[r] * b[2] + a[6 + r] * b[5] + a[12 + r] * b[8] + a[18 + r] * b[11];
-                Wt[r * 3] = w0; Wt[r * 3 + 1] = w1; Wt[r * 3 + 2] = w2;
-                Yt[r * 3] = w0 * c0 + w1 * c1 + w2 * c2;
-                Yt[r * 3 + 1] = w0 * c1 + w1 * c3 + w2 * c4;
-                Yt[r * 3 + 2] = w0 * c2 + w1 * c4 + w2 * c5;
+            for (int rr = 0; rr < 2; rr++) {
+                const int r = r0 + rr;
+                const double a0 = row[r], a1 = row[6 + r], a2 = row[12 + r], a3 = row[18 + r];
+                const double w0 = a0 * b0 + a1 * b3 + a2 * b6 + a3 * b9;
+                const double w1 = a0 * b1 + a1 * b4 + a2 * b7 + a3 * b10;
+                const double w2 = a0 * b2 + a1 * b5 + a2 * b8 + a3 * b11;
+                double* Wt = Wl + o * 18 + r * 3;
+                double* Yt = Yl + o * 18 + r * 3;
+                Wt[0] = w0; Wt[1] = w1; Wt[2] = w2;
+                Yt[0] = w0 * c0 + w1 * c1 + w2 * c2;
+                Yt[1] = w0 * c1 + w1 * c3 + w2 * c4;
+                Yt[2] = w0 * c2 + w1 * c4 + w2 * c5;
             }
-            if (my_slot != 255) tab[pl * KMAX + my_slot] = (uint8_t)tid;
         }
         __syncthreads();
         if (bi + 1 < ch.batch_end) {                 // in flight while this batch is accumulated
