@@ -21,8 +21,6 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kFactorThreads = 320;
-constexpr int kFactorQueue = 3;   // band rows in flight from HBM during the factorisation
-constexpr int kSolveQueue = 4;    // factor rows in flight during a triangular solve
 
 __device__ __forceinline__ double wave_sum(double x)
 {
@@ -55,6 +53,21 @@ __global__ __launch_bounds__(64) void bsr_to_band_kernel(const double* __restric
     const int a = t / 6, b = t % 6;
     band[((size_t)j * (bw + 1) + d) * 36 + b * 6 + a] = blocks[36 * (size_t)blk + t];
 }
+
+// e / d and e % d for small non-negative e and a RUNTIME divisor d (integer division has no hardware support and
+// costs ~40 instructions; this is ~8): float reciprocal estimate + one correction step
+struct FastDiv {
+    int d;
+    float inv;
+    __host__ __device__ explicit FastDiv(int d_) : d(d_), inv(1.0f / (float)d_) {}
+    __device__ __forceinline__ void divmod(int e, int& q, int& r) const
+    {
+        q = (int)((float)e * inv);
+        r = e - q * d;
+        if (r < 0) { q--; r += d; }
+        if (r >= d) { q++; r -= d; }
+    }
+};
 
 // 1/sqrt(s) to full f64 precision: hardware estimate + two Newton steps
 __device__ __forceinline__ double rsqrt_nr(double s)
@@ -98,32 +111,32 @@ __device__ __forceinline__ bool chol6(const double* __restrict__ A, double (&L)[
     return ok;
 }
 
+// Chunked band Cholesky.  LDS holds the rows [k0, k0 + C + bw] of the band (C pivot rows of the current chunk plus
+// the bw rows they update); the C steps of a chunk touch LDS only - no global memory operation sits inside the
+// dependent chain, so no step ever waits on s_waitcnt vmcnt.  At the chunk boundary the finished rows are written
+// out (row-oriented band, column-oriented bandT, inverse diagonal blocks) and the next C rows are read into
+// their ring slots: one exposed HBM round trip per C steps.
 __global__ __launch_bounds__(kFactorThreads) void band_cholesky_kernel(double* __restrict__ band, double* __restrict__ bandT,
-                                                                        const uint32_t n, const int bw,
+                                                                        const uint32_t n, const int bw, const int C,
                                                                         double* __restrict__ dinv, double* __restrict__ scal)
 {
-    extern __shared__ double ring[];
-    constexpr int NT = kFactorThreads, Q = kFactorQueue;
-    const int W = bw + 1, rowlen = W * 36, nslot = bw + 2;
+    extern __shared__ double lds[];
+    constexpr int NT = kFactorThreads;
+    constexpr int MAXQ = 18;                       // prefetch doubles per lane: C * rowlen / NT <= 18 (16*360/320, 8*576/320)
+    const int W = bw + 1, rowlen = W * 36, R = W + C;
+    double* ring = lds;                            // R * rowlen
+    double* lkk = ring + (size_t)R * rowlen;       // C * 36 : factor of the chunk's diagonal blocks
+    double* lki = lkk + C * 36;                    // C * 36 : their inverses
     const int tid = threadIdx.x;
-    const int e0 = tid, e1 = tid + NT;            // the (at most two) row elements this lane moves
-    const bool has0 = e0 < rowlen, has1 = e1 < rowlen;
 
-    const uint32_t pre_rows = n < (uint32_t)nslot ? n : (uint32_t)nslot;
-    for (uint32_t r = 0; r < pre_rows; r++) {
-        if (has0) ring[r * rowlen + e0] = band[(size_t)r * rowlen + e0];
-        if (has1) ring[r * rowlen + e1] = band[(size_t)r * rowlen + e1];
+    // rows 0 .. R-1
+    const FastDiv by_row(rowlen);
+    for (int e = tid; e < R * rowlen; e += NT) {
+        int row, off;
+        by_row.divmod(e, row, off);
+        ring[e] = (uint32_t)row < n ? band[(size_t)e] : 0.0;
     }
-    // register queue: rows nslot .. nslot+Q-1
-    double q0[Q], q1[Q];
-#pragma unroll
-    for (int j = 0; j < Q; j++) {
-        const uint32_t row = (uint32_t)nslot + j;
-        q0[j] = (has0 && row < n) ? band[(size_t)row * rowlen + e0] : 0.0;
-        q1[j] = (has1 && row < n) ? band[(size_t)row * rowlen + e1] : 0.0;
-    }
-    // trailing-update items of this lane: (pair of window rows, row r of the 6x6 block); pairs are ordered by
-    // their larger row so that the items of a shorter window (tail of the matrix) are a prefix
+    // trailing-update items of this lane (pair of window rows, row r of the 6x6 block), pairs ordered by larger row
     constexpr int kMaxItems = (kBandMax * (kBandMax + 1) / 2 * 6 + NT - 1) / NT;
     int it_ii[kMaxItems], it_jj[kMaxItems], it_r[kMaxItems];
 #pragma unroll
@@ -136,238 +149,236 @@ __global__ __launch_bounds__(kFactorThreads) void band_cholesky_kernel(double* _
     }
     __syncthreads();
 
-    int slot_k = 0;   // k % nslot
-    for (uint32_t k = 0; k < n; k++) {
-        double* rowk = ring + slot_k * rowlen;
-        double L[6][6], Li[6][6];
-        const bool ok = chol6(rowk, L, Li);
-        if (!ok && tid == 0) scal[SC_LIN_STATUS] = 1.0;
-        const int nb = (int)min((uint32_t)bw, n - 1 - k);
-        __syncthreads();  // every lane has read A_kk before it is overwritten below
-        if (tid < nb * 6) {
-            // panel: row r of L_ik = A_ik L_kk^-T; also stored column-oriented for the forward solve
-            const int d = 1 + tid / 6, r = tid % 6;
-            int slot_i = slot_k + d;
-            if (slot_i >= nslot) slot_i -= nslot;
-            double* a = ring + slot_i * rowlen + d * 36 + r * 6;
-            const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
-            const double x0 = a0 * Li[0][0];
-            const double x1 = a0 * Li[1][0] + a1 * Li[1][1];
-            const double x2 = a0 * Li[2][0] + a1 * Li[2][1] + a2 * Li[2][2];
-            const double x3 = a0 * Li[3][0] + a1 * Li[3][1] + a2 * Li[3][2] + a3 * Li[3][3];
-            const double x4 = a0 * Li[4][0] + a1 * Li[4][1] + a2 * Li[4][2] + a3 * Li[4][3] + a4 * Li[4][4];
-            const double x5 = a0 * Li[5][0] + a1 * Li[5][1] + a2 * Li[5][2] + a3 * Li[5][3] + a4 * Li[5][4] + a5 * Li[5][5];
-            a[0] = x0; a[1] = x1; a[2] = x2; a[3] = x3; a[4] = x4; a[5] = x5;
-            double2* o = reinterpret_cast<double2*>(bandT + ((size_t)k * W + d) * 36 + r * 6);
-            o[0] = make_double2(x0, x1); o[1] = make_double2(x2, x3); o[2] = make_double2(x4, x5);
-        } else if (tid >= 128 && tid < 128 + 36) {
-            const int e = tid - 128, r = e / 6, c = e % 6;
-            double lv = 0.0, iv = 0.0;
+    int slot_k0 = 0;   // ring slot of row k0 (k0 % R, tracked incrementally; R > C)
+    for (uint32_t k0 = 0; k0 < n; k0 += (uint32_t)C) {
+        const uint32_t next0 = k0 + (uint32_t)R;   // rows next0 .. next0 + C - 1 replace this chunk's rows at its end
+        const int csteps = (int)min((uint32_t)C, n - k0);
+        for (int kk = 0; kk < csteps; kk++) {
+            const uint32_t k = k0 + kk;
+            int slot_k = slot_k0 + kk;
+            if (slot_k >= R) slot_k -= R;
+            const double* rowk = ring + slot_k * rowlen;
+            const int nb = (int)min((uint32_t)bw, n - 1 - k);
+            if (tid < 128) {   // waves 0 and 1 hold the panel lanes and the writers of L_kk / its inverse
+                double L[6][6], Li[6][6];
+                const bool ok = chol6(rowk, L, Li);
+                if (!ok && tid == 0) scal[SC_LIN_STATUS] = 1.0;
+                if (tid < nb * 6) {
+                    // panel: row r of L_ik = A_ik L_kk^-T
+                    const int d = 1 + tid / 6, r = tid % 6;
+                    int slot_i = slot_k + d;
+                    if (slot_i >= R) slot_i -= R;
+                    double* a = ring + slot_i * rowlen + d * 36 + r * 6;
+                    const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
+                    a[0] = a0 * Li[0][0];
+                    a[1] = a0 * Li[1][0] + a1 * Li[1][1];
+                    a[2] = a0 * Li[2][0] + a1 * Li[2][1] + a2 * Li[2][2];
+                    a[3] = a0 * Li[3][0] + a1 * Li[3][1] + a2 * Li[3][2] + a3 * Li[3][3];
+                    a[4] = a0 * Li[4][0] + a1 * Li[4][1] + a2 * Li[4][2] + a3 * Li[4][3] + a4 * Li[4][4];
+                    a[5] = a0 * Li[5][0] + a1 * Li[5][1] + a2 * Li[5][2] + a3 * Li[5][3] + a4 * Li[5][4] + a5 * Li[5][5];
+                } else if (tid >= 92 && tid < 128) {
+                    const int e = tid - 92, r = e / 6, c = e % 6;
+                    double lv = 0.0, iv = 0.0;
 #pragma unroll
-            for (int rr = 0; rr < 6; rr++)
+                    for (int rr = 0; rr < 6; rr++)
 #pragma unroll
-                for (int cc = 0; cc < 6; cc++)
-                    if (rr == r && cc == c && cc <= rr) { lv = L[rr][cc]; iv = Li[rr][cc]; }
-            rowk[e] = lv;
-            dinv[36 * (size_t)k + e] = iv;
-        }
-        __syncthreads();
-        // trailing update of the window's lower block triangle: A_ij -= L_ik L_jk^T, k < j <= i <= k+nb
-        const int n_items = nb * (nb + 1) / 2 * 6;
-#pragma unroll
-        for (int s = 0; s < kMaxItems; s++) {
-            if (tid + s * NT < n_items) {
-                int slot_i = slot_k + 1 + it_ii[s], slot_j = slot_k + 1 + it_jj[s];
-                if (slot_i >= nslot) slot_i -= nslot;
-                if (slot_j >= nslot) slot_j -= nslot;
-                double* ri = ring + slot_i * rowlen;
-                const double* lik = ri + (it_ii[s] + 1) * 36 + it_r[s] * 6;
-                const double* ljk = ring + slot_j * rowlen + (it_jj[s] + 1) * 36;
-                double* tgt = ri + (it_ii[s] - it_jj[s]) * 36 + it_r[s] * 6;
-                const double l0 = lik[0], l1 = lik[1], l2 = lik[2], l3 = lik[3], l4 = lik[4], l5 = lik[5];
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    const double* lj = ljk + c * 6;
-                    tgt[c] -= l0 * lj[0] + l1 * lj[1] + l2 * lj[2] + l3 * lj[3] + l4 * lj[4] + l5 * lj[5];
+                        for (int cc = 0; cc < 6; cc++)
+                            if (rr == r && cc == c && cc <= rr) { lv = L[rr][cc]; iv = Li[rr][cc]; }
+                    lkk[kk * 36 + e] = lv;     // side buffers: A_kk itself stays intact, so no barrier before the panel
+                    lki[kk * 36 + e] = iv;
                 }
             }
-        }
-        // row k is final: store it, give its slot to the oldest row of the register queue, refill the queue
-        const uint32_t next = k + (uint32_t)nslot + Q;
-        if (has0) {
-            band[(size_t)k * rowlen + e0] = rowk[e0];
-            rowk[e0] = q0[0];
-        }
-        if (has1) {
-            band[(size_t)k * rowlen + e1] = rowk[e1];
-            rowk[e1] = q1[0];
-        }
+            __syncthreads();
+            // trailing update of the window's lower block triangle: A_ij -= L_ik L_jk^T, k < j <= i <= k+nb
+            const int n_items = nb * (nb + 1) / 2 * 6;
+#pragma unroll 1
+            for (int s = 0; s < kMaxItems; s++) {
+                if (tid + s * NT < n_items) {
+                    int slot_i = slot_k + 1 + it_ii[s], slot_j = slot_k + 1 + it_jj[s];
+                    if (slot_i >= R) slot_i -= R;
+                    if (slot_j >= R) slot_j -= R;
+                    double* ri = ring + slot_i * rowlen;
+                    const double* lik = ri + (it_ii[s] + 1) * 36 + it_r[s] * 6;
+                    const double* ljk = ring + slot_j * rowlen + (it_jj[s] + 1) * 36;
+                    double* tgt = ri + (it_ii[s] - it_jj[s]) * 36 + it_r[s] * 6;
+                    const double l0 = lik[0], l1 = lik[1], l2 = lik[2], l3 = lik[3], l4 = lik[4], l5 = lik[5];
 #pragma unroll
-        for (int j = 0; j + 1 < Q; j++) { q0[j] = q0[j + 1]; q1[j] = q1[j + 1]; }
-        q0[Q - 1] = (has0 && next < n) ? band[(size_t)next * rowlen + e0] : 0.0;
-        q1[Q - 1] = (has1 && next < n) ? band[(size_t)next * rowlen + e1] : 0.0;
-        slot_k = slot_k + 1 == nslot ? 0 : slot_k + 1;
+                    for (int c = 0; c < 6; c++) {
+                        const double* lj = ljk + c * 6;
+                        tgt[c] -= l0 * lj[0] + l1 * lj[1] + l2 * lj[2] + l3 * lj[3] + l4 * lj[4] + l5 * lj[5];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- chunk boundary: write the finished rows out, then hand their slots to the prefetched rows ----
+#pragma unroll
+        for (int s = 0; s < MAXQ; s++) {
+            int kk, off;
+            by_row.divmod(tid + s * NT, kk, off);
+            const int d = off / 36, rc = off % 36;
+            if (tid + s * NT < csteps * rowlen) {
+                const uint32_t k = k0 + kk;
+                int slot = slot_k0 + kk;
+                if (slot >= R) slot -= R;
+                // row-oriented factor row k: block 0 = L_kk, blocks d >= 1 = L_{k,k-d} (final since step k-d)
+                band[(size_t)k * rowlen + off] = d == 0 ? lkk[kk * 36 + rc] : ring[slot * rowlen + off];
+                // column-oriented: bandT[k][d] = L_{k+d,k}, which sits in row k+d (still resident), block d
+                int slot_d = slot + d;
+                if (slot_d >= R) slot_d -= R;
+                if (d >= 1 && k + d < n) bandT[(size_t)k * rowlen + off] = ring[slot_d * rowlen + off];
+            }
+        }
+        for (int e = tid; e < csteps * 36; e += NT) dinv[36 * (size_t)k0 + e] = lki[e];
+        __syncthreads();
+        // one exposed HBM round trip per chunk of C steps (amortised: ~0.1 us per step)
+#pragma unroll
+        for (int s = 0; s < MAXQ; s++) {
+            const int e = tid + s * NT;
+            if (e < C * rowlen) {
+                int row, off;
+                by_row.divmod(e, row, off);
+                int slot = slot_k0 + row;           // row k0 + R + row takes the slot of row k0 + row
+                if (slot >= R) slot -= R;
+                ring[slot * rowlen + off] = next0 + (uint32_t)row < n ? band[(size_t)next0 * rowlen + e] : 0.0;
+            }
+        }
+        slot_k0 += C;
+        if (slot_k0 >= R) slot_k0 -= R;
         __syncthreads();
     }
 }
 
-// ---- triangular solves: one wave, right-looking ------------------------------------------------------
+// ---- triangular solves: one wave, right-looking, chunked through LDS -----------------------------------
 //
 // forward  L y = b   : y_k = Linv_kk t_k, then t_{k+d} -= L_{k+d,k} y_k (bandT row k, blocks d = 1..bw)
 // backward L^T x = y : x_k = Linv_kk^T t_k, then t_{k-d} -= L_{k,k-d}^T x_k (band row k, blocks d = 1..bw)
-// t lives in an LDS ring of bw+1 blocks; lane e owns update item (d = 1 + e/6, c = e%6), and a second item
-// e + 64 when bw > 10.  ITEMS = 1 or 2.
-template <int ITEMS>
+// t lives in an LDS ring of bw+1 blocks.  A chunk of C factor rows (+ their inverse diagonal blocks and the
+// right-hand-side blocks that enter the ring) is staged in LDS; the next chunk is in flight into registers
+// meanwhile, so the C dependent steps of a chunk run without any global memory operation.
+template <int C, int IPR>   // C factor rows per chunk, IPR = ceil(max row length / 64) staged doubles per lane and row
 __device__ void band_solve_wave(const uint32_t n, const int bw, const double* __restrict__ band,
                                 const double* __restrict__ bandT, const double* __restrict__ dinv,
-                                const double* __restrict__ b, double* __restrict__ x, double* tring, double* yk)
+                                const double* __restrict__ b, double* __restrict__ x, double* lds)
 {
-    constexpr int PF = kSolveQueue;
-    const int W = bw + 1;
+    constexpr int NDI = (C * 36 + kWave - 1) / kWave;   // staged doubles per lane of the inverse diagonal blocks
+    static_assert(C * 6 <= kWave, "one lane per entering right-hand-side value");
+    const int W = bw + 1, rowlen = W * 36;
     const int lane = threadIdx.x;
     const int n_upd = bw * 6;
+    double* rows = lds;                         // C * rowlen : factor rows of the chunk
+    double* di = rows + (size_t)C * rowlen;     // C * 36
+    double* rin = di + C * 36;                  // C * 6 : blocks entering the ring during the chunk
+    double* xout = rin + C * 6;                 // C * 6 : solution blocks of the chunk
+    double* tring = xout + C * 6;               // W * 6
+    double* yk = tring + W * 6;                 // 6
 
-    // ================= forward =================
-    {
-        double lt[PF][ITEMS][6], di[PF][6], bq[PF];
-        auto load_row = [&](uint32_t row, double (&l)[ITEMS][6], double (&dv)[6], double& bv) {
+    for (int dir = 0; dir < 2; dir++) {
+        const bool fwd = dir == 0;
+        const double* fac = fwd ? bandT : band;
+        const double* rhs_in = fwd ? b : x;     // backward reads the y the forward pass left in x
+        const uint32_t n_chunk = (n + (uint32_t)C - 1) / (uint32_t)C;
+        // chunk c covers steps s = c*C .. c*C + C - 1; step s handles row k = s (forward) or n-1-s (backward)
+        auto row_of = [&](long s) -> long { return fwd ? s : (long)n - 1 - s; };
+        double qr[C][IPR], qd[NDI], qi;
+        auto fetch = [&](uint32_t c) {
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) {
-                const int e = lane + s * kWave;
-                if (e < n_upd && row + 1 + (uint32_t)(e / 6) < n) {   // block L_{row+d,row} exists
-                    const double2* p = reinterpret_cast<const double2*>(bandT + ((size_t)row * W + 1 + e / 6) * 36 + (e % 6) * 6);
-                    const double2 v0 = p[0], v1 = p[1], v2 = p[2];
-                    l[s][0] = v0.x; l[s][1] = v0.y; l[s][2] = v1.x; l[s][3] = v1.y; l[s][4] = v2.x; l[s][5] = v2.y;
-                } else {
+            for (int r = 0; r < C; r++) {
+                const long k = row_of((long)c * C + r);
+                const bool live = k >= 0 && k < (long)n;
 #pragma unroll
-                    for (int m = 0; m < 6; m++) l[s][m] = 0.0;
+                for (int i = 0; i < IPR; i++) {
+                    const int e = lane + i * kWave;
+                    qr[r][i] = (live && e < rowlen) ? fac[(size_t)k * rowlen + e] : 0.0;
                 }
             }
-            if (lane < 6 && row < n) {
-                const double2* p = reinterpret_cast<const double2*>(dinv + 36 * (size_t)row + lane * 6);
-                const double2 v0 = p[0], v1 = p[1], v2 = p[2];
-                dv[0] = v0.x; dv[1] = v0.y; dv[2] = v1.x; dv[3] = v1.y; dv[4] = v2.x; dv[5] = v2.y;
-                const uint32_t br = row + (uint32_t)W;   // the row that enters the ring when `row` leaves it
-                bv = br < n ? b[6 * (size_t)br + lane] : 0.0;
-            } else {
 #pragma unroll
-                for (int m = 0; m < 6; m++) dv[m] = 0.0;
-                bv = 0.0;
+            for (int i = 0; i < NDI; i++) {
+                const int f = lane + i * kWave;
+                const long k = row_of((long)c * C + f / 36);
+                qd[i] = (f < C * 36 && k >= 0 && k < (long)n) ? dinv[36 * (size_t)k + f % 36] : 0.0;
+            }
+            {
+                const long s = (long)c * C + lane / 6 + W;               // the step whose row enters the ring
+                const long k = row_of(s);
+                qi = (lane < C * 6 && s < (long)n && k >= 0 && k < (long)n) ? rhs_in[6 * (size_t)k + lane % 6] : 0.0;
             }
         };
-#pragma unroll
-        for (int j = 0; j < PF; j++) load_row((uint32_t)j, lt[j], di[j], bq[j]);
-        for (int e = lane; e < W * 6; e += kWave) tring[e] = (uint32_t)(e / 6) < n ? b[e] : 0.0;
         __syncthreads();
-        int slot_k = 0;
-        for (uint32_t k = 0; k < n; k++) {
-            if (lane < 6) {
-                const double* t = tring + slot_k * 6;
-                const double ya = di[0][0] * t[0] + di[0][1] * t[1] + di[0][2] * t[2] + di[0][3] * t[3] + di[0][4] * t[4] + di[0][5] * t[5];
-                yk[lane] = ya;
-                x[6 * (size_t)k + lane] = ya;
-            }
-            __syncthreads();
-            const double y0 = yk[0], y1 = yk[1], y2 = yk[2], y3 = yk[3], y4 = yk[4], y5 = yk[5];
-#pragma unroll
-            for (int s = 0; s < ITEMS; s++) {
-                const int e = lane + s * kWave;
-                if (e < n_upd) {
-                    int slot = slot_k + 1 + e / 6;
-                    if (slot >= W) slot -= W;
-                    tring[slot * 6 + e % 6] -= lt[0][s][0] * y0 + lt[0][s][1] * y1 + lt[0][s][2] * y2 + lt[0][s][3] * y3 + lt[0][s][4] * y4 + lt[0][s][5] * y5;
-                }
-            }
-            if (lane < 6) tring[slot_k * 6 + lane] = bq[0];   // row k + W takes the freed slot
-#pragma unroll
-            for (int j = 0; j + 1 < PF; j++) {
-#pragma unroll
-                for (int s = 0; s < ITEMS; s++)
-#pragma unroll
-                    for (int m = 0; m < 6; m++) lt[j][s][m] = lt[j + 1][s][m];
-#pragma unroll
-                for (int m = 0; m < 6; m++) di[j][m] = di[j + 1][m];
-                bq[j] = bq[j + 1];
-            }
-            load_row(k + PF, lt[PF - 1], di[PF - 1], bq[PF - 1]);
-            slot_k = slot_k + 1 == W ? 0 : slot_k + 1;
-            __syncthreads();
-        }
-    }
-    // ================= backward =================
-    {
-        double lr[PF][ITEMS][6], di[PF][6], yq[PF];
-        // row index runs downwards: step j handles k = n-1-j
-        auto load_row = [&](long row, double (&l)[ITEMS][6], double (&dv)[6], double& yv) {
-#pragma unroll
-            for (int s = 0; s < ITEMS; s++) {
-                const int e = lane + s * kWave;
-                if (e < n_upd && row >= 0) {
-                    // column m = e%6 of L_{row,row-d}: elements [c][m], c = 0..5
-                    const double* p = band + ((size_t)row * W + 1 + e / 6) * 36 + (e % 6);
-#pragma unroll
-                    for (int c = 0; c < 6; c++) l[s][c] = p[c * 6];
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 6; c++) l[s][c] = 0.0;
-                }
-            }
-            if (lane < 6 && row >= 0) {
-                const double* p = dinv + 36 * (size_t)row + lane;   // column `lane` of Linv
-#pragma unroll
-                for (int c = 0; c < 6; c++) dv[c] = p[c * 6];
-                const long yr = row - W;
-                yv = yr >= 0 ? x[6 * (size_t)yr + lane] : 0.0;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 6; c++) dv[c] = 0.0;
-                yv = 0.0;
-            }
-        };
-        __syncthreads();   // forward's writes of x are complete (same wave, but keep the model clean)
-#pragma unroll
-        for (int j = 0; j < PF; j++) load_row((long)n - 1 - j, lr[j], di[j], yq[j]);
-        // ring slot s holds row (n-1) - s for s = 0..bw at the start
+        // ring slot j holds the row of step j for j = 0..bw
         for (int e = lane; e < W * 6; e += kWave) {
-            const long row = (long)n - 1 - e / 6;
-            tring[e] = row >= 0 ? x[6 * (size_t)row + e % 6] : 0.0;
+            const long k = row_of(e / 6);
+            tring[e] = (e / 6 < (long)n && k >= 0 && k < (long)n) ? rhs_in[6 * (size_t)k + e % 6] : 0.0;
+        }
+        fetch(0);
+        int slot_k = 0;
+        for (uint32_t c = 0; c < n_chunk; c++) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < C; r++)
+#pragma unroll
+                for (int i = 0; i < IPR; i++) {
+                    const int e = lane + i * kWave;
+                    if (e < rowlen) rows[r * rowlen + e] = qr[r][i];
+                }
+#pragma unroll
+            for (int i = 0; i < NDI; i++) {
+                const int f = lane + i * kWave;
+                if (f < C * 36) di[f] = qd[i];
+            }
+            if (lane < C * 6) rin[lane] = qi;
+            __syncthreads();
+            if (c + 1 < n_chunk) fetch(c + 1);
+            const int csteps = (int)min((uint32_t)C, n - c * (uint32_t)C);
+            for (int kk = 0; kk < csteps; kk++) {
+                const long s = (long)c * C + kk;
+                if (lane < 6) {
+                    const double* t = tring + slot_k * 6;
+                    const double* M = di + kk * 36;
+                    double v;
+                    if (fwd) v = M[lane * 6] * t[0] + M[lane * 6 + 1] * t[1] + M[lane * 6 + 2] * t[2] + M[lane * 6 + 3] * t[3] + M[lane * 6 + 4] * t[4] + M[lane * 6 + 5] * t[5];
+                    else v = M[lane] * t[0] + M[6 + lane] * t[1] + M[12 + lane] * t[2] + M[18 + lane] * t[3] + M[24 + lane] * t[4] + M[30 + lane] * t[5];
+                    yk[lane] = v;
+                    xout[kk * 6 + lane] = v;
+                }
+                __builtin_amdgcn_s_barrier();   // one wave: a bare barrier orders the LDS traffic without draining the prefetch
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+                const double y0 = yk[0], y1 = yk[1], y2 = yk[2], y3 = yk[3], y4 = yk[4], y5 = yk[5];
+                for (int e = lane; e < n_upd; e += kWave) {
+                    const int d = 1 + e / 6, m = e % 6;
+                    if (s + d < (long)n) {
+                        int slot = slot_k + d;
+                        if (slot >= W) slot -= W;
+                        const double* l = rows + kk * rowlen + d * 36;
+                        double acc;
+                        if (fwd) {   // row m of L_{k+d,k}
+                            const double* lr = l + m * 6;
+                            acc = lr[0] * y0 + lr[1] * y1 + lr[2] * y2 + lr[3] * y3 + lr[4] * y4 + lr[5] * y5;
+                        } else {     // column m of L_{k,k-d}
+                            acc = l[m] * y0 + l[6 + m] * y1 + l[12 + m] * y2 + l[18 + m] * y3 + l[24 + m] * y4 + l[30 + m] * y5;
+                        }
+                        tring[slot * 6 + m] -= acc;
+                    }
+                }
+                if (lane < 6) tring[slot_k * 6 + lane] = rin[kk * 6 + lane];   // the row of step s + W takes the freed slot
+                slot_k = slot_k + 1 == W ? 0 : slot_k + 1;
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();
+            }
+            for (int e = lane; e < csteps * 6; e += kWave) {
+                const long k = row_of((long)c * C + e / 6);
+                x[6 * (size_t)k + e % 6] = xout[e];
+            }
         }
         __syncthreads();
-        int slot_k = 0;
-        for (long k = (long)n - 1; k >= 0; k--) {
-            if (lane < 6) {
-                const double* t = tring + slot_k * 6;
-                const double xa = di[0][0] * t[0] + di[0][1] * t[1] + di[0][2] * t[2] + di[0][3] * t[3] + di[0][4] * t[4] + di[0][5] * t[5];
-                yk[lane] = xa;
-                x[6 * (size_t)k + lane] = xa;
-            }
-            __syncthreads();
-            const double x0 = yk[0], x1 = yk[1], x2 = yk[2], x3 = yk[3], x4 = yk[4], x5 = yk[5];
-#pragma unroll
-            for (int s = 0; s < ITEMS; s++) {
-                const int e = lane + s * kWave;
-                if (e < n_upd) {
-                    int slot = slot_k + 1 + e / 6;
-                    if (slot >= W) slot -= W;
-                    tring[slot * 6 + e % 6] -= lr[0][s][0] * x0 + lr[0][s][1] * x1 + lr[0][s][2] * x2 + lr[0][s][3] * x3 + lr[0][s][4] * x4 + lr[0][s][5] * x5;
-                }
-            }
-            if (lane < 6) tring[slot_k * 6 + lane] = yq[0];   // row k - W takes the freed slot
-#pragma unroll
-            for (int j = 0; j + 1 < PF; j++) {
-#pragma unroll
-                for (int s = 0; s < ITEMS; s++)
-#pragma unroll
-                    for (int m = 0; m < 6; m++) lr[j][s][m] = lr[j + 1][s][m];
-#pragma unroll
-                for (int m = 0; m < 6; m++) di[j][m] = di[j + 1][m];
-                yq[j] = yq[j + 1];
-            }
-            load_row(k - PF, lr[PF - 1], di[PF - 1], yq[PF - 1]);
-            slot_k = slot_k + 1 == W ? 0 : slot_k + 1;
-            __syncthreads();
-        }
     }
+}
+
+__host__ __device__ inline int solve_chunk(int bw) { return bw <= 10 ? 8 : 4; }
+__host__ __device__ inline size_t solve_lds_count(int bw)
+{
+    const int C = solve_chunk(bw), W = bw + 1;
+    return (size_t)C * W * 36 + (size_t)C * 36 + (size_t)C * 6 * 2 + (size_t)W * 6 + 8;
 }
 
 // PCG state shared between the round kernels (device f64 slots behind the work vectors)
@@ -375,16 +386,17 @@ enum { PS_RZ = 0, PS_BB = 1, PS_DONE = 2, PS_ROUNDS = 3, PS_PQ = 4, PS_COUNT = 8
 
 // mode 0: plain solve x = M^-1 b.
 // mode 1: PCG round head: z = M^-1 r (z = x argument), then p = z + beta p with beta from r.z (one wave, n small)
+// mode 0: plain solve x = M^-1 b.
+// mode 1: PCG round head: z = M^-1 r (z = x argument), then p = z + beta p with beta from r.z (one wave, n small)
 __global__ __launch_bounds__(64) void band_solve_kernel(const uint32_t n, const int bw, const double* __restrict__ band,
                                                         const double* __restrict__ bandT, const double* __restrict__ dinv,
                                                         const double* __restrict__ b, double* __restrict__ x, const int mode,
                                                         double* __restrict__ p, double* __restrict__ state)
 {
-    __shared__ double tring[(kBandMax + 1) * 6];
-    __shared__ double yk[6];
+    extern __shared__ double lds[];
     if (mode == 1 && state[PS_DONE] != 0.0) return;
-    if (bw > 10) band_solve_wave<2>(n, bw, band, bandT, dinv, b, x, tring, yk);
-    else band_solve_wave<1>(n, bw, band, bandT, dinv, b, x, tring, yk);
+    if (bw <= 10) band_solve_wave<8, 7>(n, bw, band, bandT, dinv, b, x, lds);     // rows of <= 396 doubles
+    else band_solve_wave<4, 9>(n, bw, band, bandT, dinv, b, x, lds);              // rows of <= 576 doubles
     if (mode == 1) {
         __syncthreads();
         const int lane = threadIdx.x;
@@ -504,16 +516,18 @@ void launch_bsr_to_band(hipStream_t s, const BsrView& A, uint32_t n_blocks, cons
 void launch_band_cholesky(hipStream_t s, uint32_t n_rows, int bw, double* band, double* bandT, double* dinv, double* scal)
 {
     if (!n_rows) return;
-    const size_t lds = sizeof(double) * (size_t)(bw + 2) * (bw + 1) * 36;
+    const int C = bw <= 9 ? 16 : 8;   // pivot rows per LDS chunk: 75 KB at bw = 9, 110 KB at bw = 15
+    const size_t lds = sizeof(double) * ((size_t)(bw + 1 + C) * (bw + 1) * 36 + (size_t)C * 72);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_cholesky_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(kFactorThreads), lds, s, band, bandT, n_rows, bw, dinv, scal);
+    hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(kFactorThreads), lds, s, band, bandT, n_rows, bw, C, dinv, scal);
 }
 
 void launch_band_solve(hipStream_t s, uint32_t n_rows, int bw, const double* band, const double* bandT, const double* dinv,
                        const double* b, double* x)
 {
     if (!n_rows) return;
-    hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(64), 0, s, n_rows, bw, band, bandT, dinv, b, x, 0, nullptr, nullptr);
+    const size_t lds = sizeof(double) * solve_lds_count(bw);
+    hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(64), lds, s, n_rows, bw, band, bandT, dinv, b, x, 0, nullptr, nullptr);
 }
 
 void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band, const double* bandT, const double* dinv,
@@ -529,7 +543,8 @@ void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band
     hipLaunchKernelGGL(pcg_band_init_kernel, dim3(1), dim3(1024), 0, s, n, b, x, resid, state);
     for (int round = 0; round < max_rounds; round++) {
         // every kernel of a round returns at once when the previous round converged (device-side flag)
-        hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(64), 0, s, A.n_rows, bw, band, bandT, dinv, resid, z, 1, p, state);
+        hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(64), sizeof(double) * solve_lds_count(bw), s, A.n_rows, bw, band, bandT, dinv,
+                           resid, z, 1, p, state);
         hipLaunchKernelGGL(pcg_band_matvec_kernel, dim3(n_wg), dim3(256), 0, s, A, p, q, part, state);
         hipLaunchKernelGGL(pcg_band_update_kernel, dim3(1), dim3(1024), 0, s, n, n_wg, part, p, q, x, resid, state, tol, scal);
     }
