@@ -9,6 +9,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <iterator>
 #include <memory>
 #include <numeric>
@@ -61,6 +62,7 @@ struct soslam_ba {
     int kmax = 16;
     int bw = 0;                         // block half-bandwidth of the reduced camera matrix
     bool pcg_band = false;              // PCG preconditioned by the band factor
+    bool use_cr = false;                // band factor by block cyclic reduction (bw <= kCrBandMax)
     int solver = SOSLAM_SOLVER_PCG;
     double setup_seconds = 0.0;
 
@@ -86,7 +88,7 @@ struct soslam_ba {
     DevBuf<double> cams[2], pts[2];
     int cur = 0;
     DevBuf<double> campre, jc, jpr, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
-    DevBuf<double> lin_resid, lin_work, dense, band, bandT, band_dinv;
+    DevBuf<double> lin_resid, lin_work, dense, band, bandT, band_dinv, cr_ws;
     DevBuf<double> reduce_own;          // library-owned reduce buffer
     double* reduce = nullptr;           // [S blocks | rhs | diagB | gc_red | tail(4)] [scalars(SC_COUNT)]
     uint64_t reduce_main = 0;           // f64 in the per-iteration system payload
@@ -487,7 +489,13 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     } else {
         h->dense.release();
     }
-    if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) {
+    h->use_cr = (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) && h->bw >= 1 && h->bw <= kCrBandMax && nf > 0 &&
+                std::getenv("SOSLAM_NO_CR") == nullptr;
+    if (h->use_cr) {
+        SOSLAM_CHECK(h->cr_ws.alloc(cr_count(nf, h->bw)));
+        h->band.release(); h->bandT.release(); h->band_dinv.release();
+    } else if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) {
+        h->cr_ws.release();
         SOSLAM_CHECK(h->band.alloc(band_count(nf, h->bw)));
         SOSLAM_CHECK(h->bandT.alloc(band_count(nf, h->bw)));
         SOSLAM_CHECK(h->bandT.zero(s));
@@ -577,6 +585,14 @@ int take_step(soslam_ba* h, double radius)
             if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
                 launch_bsr_to_dense(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->dense.p);
                 launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
+            } else if (h->use_cr && h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
+                launch_cr_factor(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->cr_ws.p, h->scalp());
+                launch_cr_solve(s, h->n_free, h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, nullptr);
+            } else if (h->use_cr && h->pcg_band) {
+                launch_cr_factor(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->cr_ws.p, h->scalp());
+                launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
+                              h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, 2), h->scalp());
+                resid = h->lin_resid.p;
             } else if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
                 launch_bsr_to_band(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->band.p);
                 launch_band_cholesky(s, h->n_free, h->bw, h->band.p, h->bandT.p, h->band_dinv.p, h->scalp());

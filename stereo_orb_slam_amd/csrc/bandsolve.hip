@@ -430,6 +430,21 @@ __device__ __forceinline__ double bsr_row_dot(const BsrView& A, uint32_t row, co
     return s;
 }
 
+// PCG round head after an external preconditioner solve z = M^-1 r: r.z, beta, p = z + beta p (one workgroup)
+__global__ __launch_bounds__(1024) void pcg_direction_kernel(uint32_t n, const double* __restrict__ r, const double* __restrict__ z,
+                                                             double* __restrict__ p, double* __restrict__ state)
+{
+    __shared__ double red[16];
+    if (state[PS_DONE] != 0.0) return;
+    double rz = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) rz += r[i] * z[i];
+    rz = block_sum(rz, red);
+    const double beta = state[PS_ROUNDS] == 0.0 ? 0.0 : rz / state[PS_RZ];
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) p[i] = z[i] + beta * p[i];
+    __syncthreads();
+    if (threadIdx.x == 0) state[PS_RZ] = rz;
+}
+
 // x = 0, r = b, |b|^2, state reset (one workgroup)
 __global__ __launch_bounds__(1024) void pcg_band_init_kernel(uint32_t n, const double* __restrict__ b, double* __restrict__ x,
                                                              double* __restrict__ r, double* __restrict__ state)
@@ -545,6 +560,25 @@ void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band
         // every kernel of a round returns at once when the previous round converged (device-side flag)
         hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(64), sizeof(double) * solve_lds_count(bw), s, A.n_rows, bw, band, bandT, dinv,
                            resid, z, 1, p, state);
+        hipLaunchKernelGGL(pcg_band_matvec_kernel, dim3(n_wg), dim3(256), 0, s, A, p, q, part, state);
+        hipLaunchKernelGGL(pcg_band_update_kernel, dim3(1), dim3(1024), 0, s, n, n_wg, part, p, q, x, resid, state, tol, scal);
+    }
+}
+
+void launch_pcg_cr(hipStream_t s, const BsrView& A, int bw, double* cr_ws, const double* b, double* x, double* resid, double* work,
+                   double tol, int max_rounds, double* scal)
+{
+    if (!A.n_rows) return;
+    const uint32_t n = A.n_rows * 6, n_wg = (n + 255) / 256;
+    double* p = work;
+    double* z = work + n;
+    double* q = work + 2 * (size_t)n;
+    double* state = work + 3 * (size_t)n;
+    double* part = state + PS_COUNT;
+    hipLaunchKernelGGL(pcg_band_init_kernel, dim3(1), dim3(1024), 0, s, n, b, x, resid, state);
+    for (int round = 0; round < max_rounds; round++) {
+        launch_cr_solve(s, A.n_rows, bw, cr_ws, resid, z, state + PS_DONE);
+        hipLaunchKernelGGL(pcg_direction_kernel, dim3(1), dim3(1024), 0, s, n, resid, z, p, state);
         hipLaunchKernelGGL(pcg_band_matvec_kernel, dim3(n_wg), dim3(256), 0, s, A, p, q, part, state);
         hipLaunchKernelGGL(pcg_band_update_kernel, dim3(1), dim3(1024), 0, s, n, n_wg, part, p, q, x, resid, state, tol, scal);
     }
