@@ -232,7 +232,8 @@ enum {
     SOSLAM_DBG_RHS = 5,         /* 6F f64 */
     SOSLAM_DBG_STEP_CAM = 6,    /* n_cam*6 f64 (zero rows for fixed cameras) */
     SOSLAM_DBG_STEP_POINT = 7,  /* n_pt*3 f64, caller's point order */
-    SOSLAM_DBG_STEP_SCALARS = 8 /* 4 f64: cost, model_cost_change, candidate_cost, step_norm */
+    SOSLAM_DBG_STEP_SCALARS = 8 /* 6 f64: cost, model_cost_change, candidate_cost, step_norm, linear-solver
+                                   iterations, linear-solver status (0 ok) */
 };
 /* Evaluate at the current state without advancing it: linearise, and for the S/RHS/STEP items take one
  * trust-region step with `radius` and scaling from this linearisation (mirrors oracle_ba_step). */

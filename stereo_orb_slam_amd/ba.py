@@ -151,7 +151,7 @@ class BundleAdjustment:
         shape = {
             _lib.DBG_RESIDUALS: (self.n_obs, 4), _lib.DBG_JAC_CAM: (self.n_obs, 4, 6), _lib.DBG_JAC_POINT: (self.n_obs, 4, 3),
             _lib.DBG_COST: (1,), _lib.DBG_S_DENSE: (6 * F, 6 * F), _lib.DBG_RHS: (6 * F,), _lib.DBG_STEP_CAM: (self.n_cam, 6),
-            _lib.DBG_STEP_POINT: (self.n_pt, 3), _lib.DBG_STEP_SCALARS: (4,),
+            _lib.DBG_STEP_POINT: (self.n_pt, 3), _lib.DBG_STEP_SCALARS: (6,),
         }[what]
         out = np.zeros(shape)
         _lib.check(self._L.soslam_ba_debug_read(self._h, what, _lib.ptr(out), out.nbytes), "soslam_ba_debug_read")

@@ -63,6 +63,7 @@ struct soslam_ba {
     int bw = 0;                         // block half-bandwidth of the reduced camera matrix
     bool pcg_band = false;              // PCG preconditioned by the band factor
     bool use_cr = false;                // band factor by block cyclic reduction (bw <= kCrBandMax)
+    int cr_rounds = 1;                  // PCG rounds enqueued per solve with the exact band factor (see take_step)
     int solver = SOSLAM_SOLVER_PCG;
     double setup_seconds = 0.0;
 
@@ -489,6 +490,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     } else {
         h->dense.release();
     }
+    h->cr_rounds = 1;
     h->use_cr = (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) && h->bw >= 1 && h->bw <= kCrBandMax && nf > 0 &&
                 std::getenv("SOSLAM_NO_CR") == nullptr;
     if (h->use_cr) {
@@ -591,7 +593,7 @@ int take_step(soslam_ba* h, double radius)
             } else if (h->use_cr && h->pcg_band) {
                 launch_cr_factor(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->cr_ws.p, h->scalp());
                 launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
-                              h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, 2), h->scalp());
+                              h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, h->cr_rounds), h->scalp());
                 resid = h->lin_resid.p;
             } else if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
                 launch_bsr_to_band(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->band.p);
@@ -639,6 +641,11 @@ int take_step(soslam_ba* h, double radius)
         SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
     }
     SOSLAM_HIP_CHECK(hipGetLastError());
+    // The band factor is exact, so one PCG round (= a direct solve plus the true residual) normally meets the
+    // tolerance.  Rounds are enqueued without host checks; if this solve fell short - the step is still a valid
+    // inexact step, its residual enters the model cost change - later solves enqueue one round more.
+    if (h->use_cr && h->pcg_band && h->n_free && h->host_scal[SC_LIN_RESID] > h->opt.pcg_tolerance && h->cr_rounds < 4)
+        h->cr_rounds++;
     return SOSLAM_OK;
 }
 
@@ -1153,9 +1160,10 @@ int soslam_ba_debug_read(soslam_ba* h, int32_t what, void* dst, uint64_t bytes)
         return SOSLAM_OK;
     }
     case SOSLAM_DBG_STEP_SCALARS: {
-        SOSLAM_CHECK(need(4 * sizeof(double)));
+        SOSLAM_CHECK(need(6 * sizeof(double)));
         const StepScalars sc = read_scalars(h);
         out[0] = sc.x_cost; out[1] = sc.mcc; out[2] = sc.cand_cost; out[3] = sc.step_norm;
+        out[4] = (double)sc.lin_iters; out[5] = (double)sc.lin_status;
         return SOSLAM_OK;
     }
     default:

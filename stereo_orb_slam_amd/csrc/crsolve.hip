@@ -2,14 +2,19 @@
 //
 // A band of half-width bw blocks is block TRIDIAGONAL in super-blocks of bw cameras (sb = 6 bw scalars).  The
 // sequential band Cholesky needs n dependent block steps on one CU (latency-bound: ~2 us per step, 1.2 ms at 499
-// cameras).  Cyclic reduction instead eliminates every other super-block of the current level IN PARALLEL, one
-// workgroup per super-block, and halves the system per level: ceil(log2 m) levels of two kernels each
-// (m = 56 super-blocks at BASELINE.json configs[2]).  Per eliminated node i with neighbours i-h, i+h:
-//     D_i = L_i L_i^T,  Linv_i = L_i^-1,  U_i = Linv_i F_i,  V_i = Linv_i G_i^T      (F_i = A(i,i-h), G_i = A(i+h,i) = F_{i+h})
-// per remaining node k:   D_k -= V_{k-h}^T V_{k-h} + U_{k+h}^T U_{k+h},   F_k <- -V_{k-h}^T U_{k-h}   (fill: A(k,k-2h))
-// Storing the INVERSE factor turns every later triangular solve into a matrix-vector product, so a solve is
-// 2 ceil(log2 m) + 1 small launches without any dependent chain.  All sums run in a fixed order: bitwise
-// reproducible.  Positive definiteness is inherited by every Schur complement, so no pivoting is needed.
+// cameras).  Cyclic reduction instead eliminates every other super-block of the current level IN PARALLEL and halves
+// the system per level: ceil(log2 m) levels of two kernels each (m = 56 super-blocks at BASELINE.json configs[2]).
+//
+// Level h, eliminated nodes i = h (2j+1), remaining nodes k = 2 h j, F_n = A(n, n-h) the coupling to the left:
+//   cr_invert : E_i = D_i^-1                       (block Gauss-Jordan sweep in LDS, 6x6 pivots, one workgroup per node)
+//   cr_reduce : per remaining k with a = k-h, c = k+h (f64 matrix cores, one workgroup per 16 columns of the node)
+//                 Q_a = E_a F_k^T        P_c = E_c F_c
+//                 D_k -= F_k Q_a + F_c^T P_c        F_k <- -Q_a^T F_a      (fill: A(k, k-2h))
+// Each product is owned by exactly one remaining node.  With the explicit inverse every step of a later solve is a
+// matrix-vector product:   forward   w_k -= Q_a^T w_a + P_c^T w_c      backward   x_i = E_i w_i - P_i x_{i-h} - Q_i x_{i+h}
+// i.e. 2 ceil(log2 m) + 1 small launches without any dependent chain inside a launch.  All sums run in a fixed
+// order: bitwise reproducible.  Positive definiteness is inherited by every Schur complement, so the sweep needs no
+// pivoting; a non-positive 6x6 pivot block raises scal[SC_LIN_STATUS].
 #include "linsolve.h"
 
 #include "ba_kernels.h"
@@ -18,7 +23,7 @@ namespace soslam {
 
 namespace {
 
-constexpr int kCrThreads = 512;
+constexpr int kCrReduceThreads = 256;
 
 __device__ __forceinline__ double rsqrt_nr(double s)
 {
@@ -61,8 +66,10 @@ __device__ __forceinline__ bool chol6_lds(const double* __restrict__ A, int lda,
     return ok;
 }
 
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
-constexpr int kLd = 64;   // leading dimension of the zero-padded LDS images fed to the matrix cores (sb <= 60)
+constexpr int kLd = 65;   // leading dimension of the zero-padded LDS images fed to the matrix cores (sb <= 60): odd, so that
+                          // transposed staging writes are conflict-free; 16 consecutive doubles of a row still cover every bank once
 
 // One 16x16 tile of C = P^T Q on the f64 matrix cores: C[i0+i][j0+j] = sum_m P[m][i0+i] Q[m][j0+j], m < kp (multiple
 // of 4), P and Q zero-padded LDS images with leading dimension kLd.  v_mfma_f64_16x16x4_f64 register layout
@@ -81,7 +88,7 @@ __device__ __forceinline__ double4_t mfma_ptq_tile(const double* __restrict__ P,
 struct CrView {
     uint32_t m;       // super-blocks
     int bw, sb;       // cameras per super-block, scalars per super-block
-    double *D, *F, *Linv, *U, *V;   // each [m][sb*sb], row-major
+    double *D, *F, *E, *P, *Q, *PT, *QT;   // each [m][sb*sb], row-major; P, Q (and transposes) indexed by the eliminated node
 };
 
 // scatter the upper block-sparse S into D (diagonal super-blocks) and F (F_i = A(i, i-1)); pad with identity
@@ -115,137 +122,137 @@ __global__ __launch_bounds__(64) void cr_assemble_kernel(const double* __restric
     }
 }
 
-// Eliminated node i = h (2 j + 1)  (or node 0 when final != 0): Cholesky of D_i in LDS, inverse factor, U_i, V_i.
-__global__ __launch_bounds__(kCrThreads) void cr_factor_kernel(const CrView v, const uint32_t h, const int final_node,
-                                                               double* __restrict__ scal)
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Eliminated node i = h (2 j + 1)  (or node 0 when final != 0): E_i = D_i^-1 by a block Gauss-Jordan sweep.
+// Sweeping the 3x3 pivot block K of a matrix turns   A_KK -> A_KK^-1,  A_Kj -> A_KK^-1 A_Kj,  A_iK -> -A_iK A_KK^-1,
+// A_ij -> A_ij - A_iK A_KK^-1 A_Kj;  after all 2 bw pivot blocks the array holds A^-1.
+// The matrix lives in REGISTERS: wave jb owns the 6-column segment jb, lane = row, six doubles per lane.  What a
+// step costs is the instruction stream of its slowest wave, so the shared part is done once: the wave that owns the
+// pivot columns takes the pivot block from its own lanes (v_readlane), inverts it in closed form, and publishes
+// G = A_iK A_KK^-1 (rows of -A_KK^-1 on the pivot rows) through a double-buffered LDS strip - one barrier per pivot
+// block.  Every wave then reads its three G values and takes the pivot rows A_Kj of its own segment from its own
+// lanes (v_readlane again, no LDS).
+constexpr int kCrInvertThreadsMax = 64 * kCrBandMax;
+
+__global__ __launch_bounds__(kCrInvertThreadsMax) void cr_invert_kernel(const CrView v, const uint32_t h, const int final_node,
+                                                                        double* __restrict__ scal)
 {
     extern __shared__ double lds[];
-    const int sb = v.sb, bw = v.bw, tid = threadIdx.x;
+    const int sb = v.sb, bw = v.bw, ld = sb | 1;
+    const int row = threadIdx.x % 64, jb = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);   // blockDim = 64 bw
     const size_t sb2 = (size_t)sb * sb;
     const uint32_t i = final_node ? 0u : h * (2 * blockIdx.x + 1);
     if (i >= v.m) return;
-    const bool has_left = !final_node && i >= h, has_right = !final_node && i + h < v.m;
-    const int kp = (sb + 3) & ~3;  // summation length padded to the matrix cores' k = 4
-    double* A = lds;               // sb*sb : D_i, then L_i (lower)
-    double* X = A + sb2;           // sb*sb : Linv_i
-    double* XT = X + sb2;          // kp*kLd : Linv_i^T, zero-padded
-    double* T = XT + kp * kLd;     // kp*kLd : staged F_i / G_i^T, zero-padded
-    double* LiD = T + kp * kLd;    // bw*36 : inverses of the diagonal 6x6 factor blocks
-    double* Tb = LiD + bw * 36;    // bw*36 : scratch of the blocked inversion
-
-    for (int e = tid; e < sb * sb; e += kCrThreads) { A[e] = v.D[i * sb2 + e]; X[e] = 0.0; }
+    double* X = lds;                          // sb x ld staging image (odd row stride: conflict-free column access)
+    double* pc = lds + (size_t)sb * ld;       // [2][64][3] strips of G
+    const bool live = row < sb;
+    {
+        // coalesced: wave jb takes rows jb, jb + bw, ..; every load is issued before the first LDS write
+        const double* src = v.D + i * sb2;
+        double tmp[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) tmp[u] = live ? src[(size_t)(jb + u * bw) * sb + row] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 6; u++) if (live) X[(jb + u * bw) * ld + row] = tmp[u];
+    }
     __syncthreads();
+    double x[6];
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) x[cc] = live ? X[row * ld + jb * 6 + cc] : 0.0;
 
-    // ---- blocked right-looking Cholesky, 6x6 blocks -------------------------------------------------------
-    for (int kb = 0; kb < bw; kb++) {
-        double L[6][6], Li[6][6];
-        const bool ok = chol6_lds(A + (size_t)(kb * 6) * sb + kb * 6, sb, L, Li);
-        if (!ok && tid == 0) scal[SC_LIN_STATUS] = 1.0;
-        const int nb = bw - 1 - kb;
-        __syncthreads();   // every lane has read A_kk
-        if (tid < nb * 6) {
-            double* a = A + (size_t)((kb + 1) * 6 + tid) * sb + kb * 6;   // row (kb+1)*6 + tid of the panel
-            const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
-            a[0] = a0 * Li[0][0];
-            a[1] = a0 * Li[1][0] + a1 * Li[1][1];
-            a[2] = a0 * Li[2][0] + a1 * Li[2][1] + a2 * Li[2][2];
-            a[3] = a0 * Li[3][0] + a1 * Li[3][1] + a2 * Li[3][2] + a3 * Li[3][3];
-            a[4] = a0 * Li[4][0] + a1 * Li[4][1] + a2 * Li[4][2] + a3 * Li[4][3] + a4 * Li[4][4];
-            a[5] = a0 * Li[5][0] + a1 * Li[5][1] + a2 * Li[5][2] + a3 * Li[5][3] + a4 * Li[5][4] + a5 * Li[5][5];
-        } else if (tid >= 128 && tid < 128 + 36) {
-            const int e = tid - 128, r = e / 6, c = e % 6;
-            double lv = 0.0, iv = 0.0;
-#pragma unroll
-            for (int rr = 0; rr < 6; rr++)
-#pragma unroll
-                for (int cc = 0; cc < 6; cc++)
-                    if (rr == r && cc == c && cc <= rr) { lv = L[rr][cc]; iv = Li[rr][cc]; }
-            A[(size_t)(kb * 6 + r) * sb + kb * 6 + c] = lv;
-            LiD[kb * 36 + e] = iv;
+    bool ok = true;
+    int buf = 0;
+    for (int kb = 0; kb < 2 * bw; kb++) {
+        const int k0 = kb * 3, jbk = k0 / 6;
+        const bool second = (k0 - jbk * 6) != 0;   // pivot columns are x[3..5] (else x[0..2]) of wave jbk
+        const bool pwave = jb == jbk;
+        double* strip = pc + buf * 192;
+        if (pwave) {
+            const double p0 = second ? x[3] : x[0], p1 = second ? x[4] : x[1], p2 = second ? x[5] : x[2];
+            // pivot block = rows k0..k0+2 of the pivot columns: lanes k0..k0+2 of this wave
+            const double m[6] = {readlane_f64(p0, k0), readlane_f64(p1, k0), readlane_f64(p2, k0),
+                                 readlane_f64(p1, k0 + 1), readlane_f64(p2, k0 + 1), readlane_f64(p2, k0 + 2)};
+            double Pi[6];
+            ok = sym3_inverse(m, Pi) && ok;     // xx xy xz yy yz zz
+            const int r = row - k0;             // 0..2 on a pivot row
+            const bool prow = r >= 0 && r < 3;
+            // G row = a Pi with a = A_iK, or -e_r on a pivot row (so that the row is -Pi[r][:])
+            const double a0 = prow ? (r == 0 ? -1.0 : 0.0) : p0;
+            const double a1 = prow ? (r == 1 ? -1.0 : 0.0) : p1;
+            const double a2 = prow ? (r == 2 ? -1.0 : 0.0) : p2;
+            strip[row * 3 + 0] = a0 * Pi[0] + a1 * Pi[1] + a2 * Pi[2];
+            strip[row * 3 + 1] = a0 * Pi[1] + a1 * Pi[3] + a2 * Pi[4];
+            strip[row * 3 + 2] = a0 * Pi[2] + a1 * Pi[4] + a2 * Pi[5];
         }
         __syncthreads();
-        // trailing update: A_ij -= L_ik L_jk^T for block rows kb < jb <= ib; one lane per (pair, row)
-        const int n_items = nb * (nb + 1) / 2 * 6;
-        for (int item = tid; item < n_items; item += kCrThreads) {
-            const int pair = item / 6, r = item % 6;
-            int ii = (int)((sqrtf(8.0f * (float)pair + 1.0f) - 1.0f) * 0.5f);
-            while ((ii + 1) * (ii + 2) / 2 <= pair) ii++;
-            while (ii * (ii + 1) / 2 > pair) ii--;
-            const int jj = pair - ii * (ii + 1) / 2;
-            const int ib = kb + 1 + ii, jb = kb + 1 + jj;
-            const double* lik = A + (size_t)(ib * 6 + r) * sb + kb * 6;
-            double* tgt = A + (size_t)(ib * 6 + r) * sb + jb * 6;
-            const double l0 = lik[0], l1 = lik[1], l2 = lik[2], l3 = lik[3], l4 = lik[4], l5 = lik[5];
+        const double g0 = strip[row * 3 + 0], g1 = strip[row * 3 + 1], g2 = strip[row * 3 + 2];
+        const bool prow = row >= k0 && row < k0 + 3;
+        // x = base - g Z with Z = A_Kj from this wave's own lanes, base = A_ij (zero on the pivot rows); branch-free.
+        // The pivot columns (three registers of the pivot wave) are then overwritten with -g.
 #pragma unroll
-            for (int c = 0; c < 6; c++) {
-                const double* lj = A + (size_t)(jb * 6 + c) * sb + kb * 6;
-                tgt[c] -= l0 * lj[0] + l1 * lj[1] + l2 * lj[2] + l3 * lj[3] + l4 * lj[4] + l5 * lj[5];
-            }
+        for (int cc = 0; cc < 6; cc++) {
+            const double z0 = readlane_f64(x[cc], k0 + 0);
+            const double z1 = readlane_f64(x[cc], k0 + 1);
+            const double z2 = readlane_f64(x[cc], k0 + 2);
+            const double base = prow ? 0.0 : x[cc];
+            x[cc] = base - (g0 * z0 + g1 * z1 + g2 * z2);
         }
-        __syncthreads();
+        if (pwave) {
+            if (second) { x[3] = -g0; x[4] = -g1; x[5] = -g2; }
+            else        { x[0] = -g0; x[1] = -g1; x[2] = -g2; }
+        }
+        buf ^= 1;
     }
-
-    // ---- blocked inversion of the lower factor: X[rb][cb] = -Li_rb * sum_{kb=cb}^{rb-1} L[rb][kb] X[kb][cb] ---------
-    for (int rb = 0; rb < bw; rb++) {
-        if (tid < 36) X[(size_t)(rb * 6 + tid / 6) * sb + rb * 6 + tid % 6] = LiD[rb * 36 + tid];
-        for (int e = tid; e < rb * 36; e += kCrThreads) {
-            const int cb = e / 36, r = (e % 36) / 6, c = e % 6;
-            double s = 0.0;
-            for (int kb = cb; kb < rb; kb++) {
-                const double* l = A + (size_t)(rb * 6 + r) * sb + kb * 6;
-                const double* x = X + (size_t)(kb * 6) * sb + cb * 6 + c;
+    if (!ok && row == 0) scal[SC_LIN_STATUS] = 1.0;
+    // symmetric to rounding; store the symmetrised inverse (coalesced, through the staging image)
+    __syncthreads();
 #pragma unroll
-                for (int m = 0; m < 6; m++) s += l[m] * x[(size_t)m * sb];
-            }
-            Tb[e] = s;
-        }
-        __syncthreads();
-        for (int e = tid; e < rb * 36; e += kCrThreads) {
-            const int cb = e / 36, r = (e % 36) / 6, c = e % 6;
-            const double* li = LiD + rb * 36 + r * 6;
-            const double* t = Tb + cb * 36 + c;
-            double s = 0.0;
+    for (int cc = 0; cc < 6; cc++) if (live) X[row * ld + jb * 6 + cc] = x[cc];
+    __syncthreads();
+    if (live) {
+        double* dst = v.E + i * sb2;
 #pragma unroll
-            for (int m = 0; m < 6; m++) s += li[m] * t[m * 6];
-            X[(size_t)(rb * 6 + r) * sb + cb * 6 + c] = -s;
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < sb * sb; e += kCrThreads) v.Linv[i * sb2 + e] = X[e];
-
-    // ---- U_i = Linv F_i and V_i = Linv G_i^T on the matrix cores: out = (Linv^T)^T T ---------------------------
-    for (int e = tid; e < kp * kLd; e += kCrThreads) {
-        const int k = e / kLd, r = e % kLd;
-        XT[e] = (k < sb && r < sb) ? X[(size_t)r * sb + k] : 0.0;
-    }
-    for (int side = 0; side < 2; side++) {
-        const bool on = side == 0 ? has_left : has_right;
-        if (!on) continue;   // uniform
-        __syncthreads();
-        const double* src = side == 0 ? v.F + i * sb2 : v.F + (i + h) * sb2;   // G_i = A(i+h, i) = F_{i+h}, used transposed
-        for (int e = tid; e < kp * kLd; e += kCrThreads) {
-            const int k = e / kLd, c = e % kLd;
-            T[e] = (k < sb && c < sb) ? (side == 0 ? src[(size_t)k * sb + c] : src[(size_t)c * sb + k]) : 0.0;
-        }
-        __syncthreads();
-        double* out = (side == 0 ? v.U : v.V) + i * sb2;
-        const int wave = tid / 64, lane = tid % 64;
-        const int nt = (sb + 15) / 16;
-        for (int t = wave; t < nt * nt; t += kCrThreads / 64) {
-            const int i0 = (t / nt) * 16, j0 = (t % nt) * 16;
-            // Linv is lower triangular: rows i0..i0+15 only reach k <= i0 + 15
-            const double4_t acc = mfma_ptq_tile(XT, T, min(kp, (i0 + 16 + 3) & ~3), i0, j0, lane);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = i0 + 4 * r + lane / 16, col = j0 + lane % 16;
-                if (row < sb && col < sb) out[(size_t)row * sb + col] = acc[r];
-            }
+        for (int u = 0; u < 6; u++) {
+            const int r2 = jb + u * bw;
+            dst[(size_t)r2 * sb + row] = 0.5 * (X[r2 * ld + row] + X[row * ld + r2]);
         }
     }
 }
 
-// Remaining node k = 2 h j: D_k -= V_a^T V_a + U_c^T U_c (a = k-h, c = k+h), F_k <- -V_a^T U_a
-__global__ __launch_bounds__(kCrThreads) void cr_update_kernel(const CrView v, const uint32_t h)
+// Remaining node k = 2 h j, column tile q = blockIdx.y (16 columns of every product), one wave per 16-row tile.
+// All five operand matrices are requested from memory before the first LDS write (one latency, not five).
+constexpr int kStageRegs = 60 / (kCrReduceThreads / 64);   // rows per wave at sb = 60: 15
+
+struct StageRegs { double v[kStageRegs]; };
+
+// wave w requests rows w, w + 4, .. (lane = column): coalesced, no index arithmetic beyond adds
+__device__ __forceinline__ void stage_load(StageRegs& r, const double* __restrict__ src, int sb, int wave, int lane, bool on)
+{
+#pragma unroll
+    for (int u = 0; u < kStageRegs; u++) {
+        const int row = wave + u * (kCrReduceThreads / 64);
+        r.v[u] = (on && row < sb && lane < sb) ? src[(size_t)row * sb + lane] : 0.0;
+    }
+}
+
+// registers -> LDS image with leading dimension kLd (the padding was zeroed beforehand); transposed on request
+__device__ __forceinline__ void stage_store(const StageRegs& r, double* __restrict__ dst, int sb, int wave, int lane, bool transpose)
+{
+#pragma unroll
+    for (int u = 0; u < kStageRegs; u++) {
+        const int row = wave + u * (kCrReduceThreads / 64);
+        if (row < sb && lane < sb) dst[transpose ? lane * kLd + row : row * kLd + lane] = r.v[u];
+    }
+}
+
+__global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrView v, const uint32_t h)
 {
     extern __shared__ double lds[];
     const int sb = v.sb, tid = threadIdx.x;
@@ -254,50 +261,79 @@ __global__ __launch_bounds__(kCrThreads) void cr_update_kernel(const CrView v, c
     if (k >= v.m) return;
     const bool has_a = k >= h, has_c = k + h < v.m;
     if (!has_a && !has_c) return;
+    const uint32_t a = has_a ? k - h : 0, c = has_c ? k + h : 0;
+    const bool fill = has_a && a >= h;   // node a had a left neighbour a-h = k-2h: new coupling A(k, k-2h)
     const int kp = (sb + 3) & ~3;
-    double* P = lds;                 // kp*kLd : V_a or U_c, zero-padded
-    double* Q = P + kp * kLd;        // kp*kLd : U_a
+    const int nt = (sb + 15) / 16;          // 16-wide tiles per dimension (<= 4)
     const int wave = tid / 64, lane = tid % 64;
-    const int nt = (sb + 15) / 16;
-    auto stage = [&](double* dst, const double* src) {
-        for (int e = tid; e < kp * kLd; e += kCrThreads) {
-            const int r = e / kLd, c = e % kLd;
-            dst[e] = (r < sb && c < sb) ? src[(size_t)r * sb + c] : 0.0;
+    const int q0 = (int)blockIdx.y * 16;     // this workgroup's column tile
+    const int w0 = wave * 16;                // this wave's row tile
+    const bool active = wave < nt;
+    double* B0 = lds;
+    double* B1 = B0 + kp * kLd;
+    double* B2 = B1 + kp * kLd;
+    double* B3 = B2 + kp * kLd;
+
+    StageRegs rEa, rFk, rFa, rEc, rFc;
+    stage_load(rEa, v.E + a * sb2, sb, wave, lane, has_a);
+    stage_load(rFk, v.F + k * sb2, sb, wave, lane, has_a);
+    stage_load(rFa, v.F + a * sb2, sb, wave, lane, fill);
+    stage_load(rEc, v.E + c * sb2, sb, wave, lane, has_c);
+    stage_load(rFc, v.F + c * sb2, sb, wave, lane, has_c);
+    double dk[4];   // this wave's tile of D_k
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = w0 + 4 * r + lane / 16, col = q0 + lane % 16;
+        dk[r] = (active && row < sb && col < sb) ? v.D[k * sb2 + (size_t)row * sb + col] : 0.0;
+    }
+    for (int e = tid; e < 4 * kp * kLd; e += kCrReduceThreads) lds[e] = 0.0;
+    __syncthreads();
+
+    // tile (rows i0.., cols j0..) of the accumulator to global row-major (+ optionally transposed) and to an LDS image
+    auto put = [&](const double4_t acc, int i0, int j0, double* out, double* outT, double* img, double sign) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = i0 + 4 * r + lane / 16, col = j0 + lane % 16;
+            const double val = sign * acc[r];
+            if (img && row < kp) img[row * kLd + col] = val;
+            if (row < sb && col < sb) {
+                if (out) out[(size_t)row * sb + col] = val;
+                if (outT) outT[(size_t)col * sb + row] = val;
+            }
         }
     };
+    double4_t dacc = {0.0, 0.0, 0.0, 0.0};   // this wave's tile (w0, q0) of the update of D_k
     if (has_a) {
-        const uint32_t a = k - h;
-        const bool fill = a >= h;   // node a had a left neighbour a-h = k-2h: new coupling A(k, k-2h)
-        stage(P, v.V + a * sb2);
-        if (fill) stage(Q, v.U + a * sb2);
+        stage_store(rEa, B0, sb, wave, lane, false);
+        stage_store(rFk, B1, sb, wave, lane, true);             // B1[m][i] = F_k[i][m]
+        if (fill) stage_store(rFa, B3, sb, wave, lane, false);
         __syncthreads();
-        for (int t = wave; t < nt * nt; t += kCrThreads / 64) {
-            const int i0 = (t / nt) * 16, j0 = (t % nt) * 16;
-            const double4_t s = mfma_ptq_tile(P, P, kp, i0, j0, lane);
-            double4_t f = {0.0, 0.0, 0.0, 0.0};
-            if (fill) f = mfma_ptq_tile(P, Q, kp, i0, j0, lane);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = i0 + 4 * r + lane / 16, col = j0 + lane % 16;
-                if (row < sb && col < sb) {
-                    v.D[k * sb2 + (size_t)row * sb + col] -= s[r];
-                    if (fill) v.F[k * sb2 + (size_t)row * sb + col] = -f[r];
-                }
-            }
+        if (active) put(mfma_ptq_tile(B0, B1, kp, w0, q0, lane), w0, q0, v.Q + a * sb2, v.QT + a * sb2, B2, 1.0);   // Q_a[:, q]
+        __syncthreads();
+        if (active) {
+            dacc = mfma_ptq_tile(B1, B2, kp, w0, q0, lane);                                   // (F_k Q_a)[w, q]
+            // rows q of the fill: -(Q_a[:, q])^T F_a, this wave takes column tile w
+            if (fill) put(mfma_ptq_tile(B2, B3, kp, q0, w0, lane), q0, w0, v.F + k * sb2, nullptr, nullptr, -1.0);
         }
         __syncthreads();
     }
     if (has_c) {
-        stage(P, v.U + (k + h) * sb2);
+        stage_store(rEc, B0, sb, wave, lane, false);
+        stage_store(rFc, B1, sb, wave, lane, false);
         __syncthreads();
-        for (int t = wave; t < nt * nt; t += kCrThreads / 64) {
-            const int i0 = (t / nt) * 16, j0 = (t % nt) * 16;
-            const double4_t s = mfma_ptq_tile(P, P, kp, i0, j0, lane);
+        if (active) put(mfma_ptq_tile(B0, B1, kp, w0, q0, lane), w0, q0, v.P + c * sb2, v.PT + c * sb2, B2, 1.0);   // P_c[:, q]
+        __syncthreads();
+        if (active) {
+            const double4_t s = mfma_ptq_tile(B1, B2, kp, w0, q0, lane);                      // (F_c^T P_c)[w, q]
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = i0 + 4 * r + lane / 16, col = j0 + lane % 16;
-                if (row < sb && col < sb) v.D[k * sb2 + (size_t)row * sb + col] -= s[r];
-            }
+            for (int r = 0; r < 4; r++) dacc[r] += s[r];
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = w0 + 4 * r + lane / 16, col = q0 + lane % 16;
+            if (row < sb && col < sb) v.D[k * sb2 + (size_t)row * sb + col] = dk[r] - dacc[r];
         }
     }
 }
@@ -307,100 +343,85 @@ __global__ __launch_bounds__(kCrThreads) void cr_update_kernel(const CrView v, c
 
 __device__ __forceinline__ bool cr_done(const double* __restrict__ done_flag) { return done_flag && *done_flag != 0.0; }
 
-// The solve kernels use 256 lanes per node: lane (t = tid % 64, g = tid / 64) sums a quarter of the products of
-// output element t, the quarters are added in a fixed order through LDS.  Four times the loads in flight of a
-// one-lane-per-element loop - these kernels are pure latency.
-__device__ __forceinline__ double quarter_sum(double part, double (*red)[64], int t, int g)
+// The solve kernels use 512 lanes per node: wave g of 8 sums every 8th product of output element t = lane (operator
+// columns: consecutive lanes read consecutive doubles; the vector element is wave-uniform, a scalar load), all loads
+// of a lane are issued before its first multiply, and the eight partial sums are added in a fixed order through
+// LDS.  These kernels are pure latency: one memory round trip each.
+constexpr int kCrSolveThreads = 512;
+constexpr int kCrSolveGroups = kCrSolveThreads / 64;
+constexpr int kCrSolveIters = (60 + kCrSolveGroups - 1) / kCrSolveGroups;   // 8 products per lane and operator at sb = 60
+
+__device__ __forceinline__ double group_sum(double part, double (*red)[64], int t, int g)
 {
     red[g][t] = part;
     __syncthreads();
-    return red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    double s = red[0][t];
+#pragma unroll
+    for (int q = 1; q < kCrSolveGroups; q++) s += red[q][t];
+    return s;
 }
 
-// forward, eliminated node i: y_i = Linv_i w_i   (in place)
-__global__ __launch_bounds__(256) void cr_fwd_kernel(const CrView v, const uint32_t h, const int final_node, double* __restrict__ w,
-                                                     const double* __restrict__ done_flag)
+struct ColOp { double m[kCrSolveIters], y[kCrSolveIters]; };
+
+// request M[m][t] and y[m] for m = g, g + 8, ..
+__device__ __forceinline__ void col_load(ColOp& o, const double* __restrict__ M, const double* __restrict__ y, int sb, int t, int g,
+                                         bool on)
 {
-    __shared__ double wl[64];
-    __shared__ double red[4][64];
-    if (cr_done(done_flag)) return;
-    const int sb = v.sb, t = threadIdx.x % 64, g = threadIdx.x / 64;
-    const uint32_t i = final_node ? 0u : h * (2 * blockIdx.x + 1);
-    if (i >= v.m) return;
-    if (threadIdx.x < sb) wl[threadIdx.x] = w[(size_t)i * sb + threadIdx.x];
-    __syncthreads();
-    double s = 0.0;
-    if (t < sb) {
-        const double* M = v.Linv + (size_t)i * sb * sb + (size_t)t * sb;   // row t, columns 0..t
-        for (int k = g; k <= t; k += 4) s += M[k] * wl[k];
+#pragma unroll
+    for (int u = 0; u < kCrSolveIters; u++) {
+        const int m = g + u * kCrSolveGroups;
+        const bool in = on && m < sb && t < sb;
+        o.m[u] = in ? M[(size_t)m * sb + t] : 0.0;
+        o.y[u] = in ? y[m] : 0.0;
     }
-    s = quarter_sum(s, red, t, g);
-    if (g == 0 && t < sb) w[(size_t)i * sb + t] = s;
 }
 
-// forward, remaining node k: w_k -= V_a^T y_a + U_c^T y_c
-__global__ __launch_bounds__(256) void cr_fwd_update_kernel(const CrView v, const uint32_t h, double* __restrict__ w,
-                                                            const double* __restrict__ done_flag)
+__device__ __forceinline__ double col_dot(const ColOp& o)
 {
-    __shared__ double red[4][64];
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < kCrSolveIters; u++) s += o.m[u] * o.y[u];
+    return s;
+}
+
+// forward, remaining node k: w_k -= Q_a^T w_a + P_c^T w_c
+__global__ __launch_bounds__(kCrSolveThreads) void cr_fwd_kernel(const CrView v, const uint32_t h, double* __restrict__ w,
+                                                                 const double* __restrict__ done_flag)
+{
+    __shared__ double red[kCrSolveGroups][64];
     if (cr_done(done_flag)) return;
-    const int sb = v.sb, t = threadIdx.x % 64, g = threadIdx.x / 64;
+    const int sb = v.sb, t = threadIdx.x % 64, g = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
     const size_t sb2 = (size_t)sb * sb;
     const uint32_t k = 2 * h * blockIdx.x;
     if (k >= v.m) return;
-    double s = 0.0;
-    if (t < sb) {
-        if (k >= h) {
-            const uint32_t a = k - h;
-            const double* M = v.V + a * sb2 + t;
-            const double* y = w + (size_t)a * sb;
-            for (int m = g; m < sb; m += 4) s += M[(size_t)m * sb] * y[m];
-        }
-        if (k + h < v.m) {
-            const uint32_t c = k + h;
-            const double* M = v.U + c * sb2 + t;
-            const double* y = w + (size_t)c * sb;
-            for (int m = g; m < sb; m += 4) s += M[(size_t)m * sb] * y[m];
-        }
-    }
-    s = quarter_sum(s, red, t, g);
-    if (g == 0 && t < sb) w[(size_t)k * sb + t] -= s;
+    const bool has_a = k >= h, has_c = k + h < v.m;
+    const uint32_t a = has_a ? k - h : 0, c = has_c ? k + h : 0;
+    ColOp oa, oc;
+    col_load(oa, v.Q + a * sb2, w + (size_t)a * sb, sb, t, g, has_a);
+    col_load(oc, v.P + c * sb2, w + (size_t)c * sb, sb, t, g, has_c);
+    const double wk = (g == 0 && t < sb) ? w[(size_t)k * sb + t] : 0.0;
+    const double s = group_sum(col_dot(oa) + col_dot(oc), red, t, g);
+    if (g == 0 && t < sb) w[(size_t)k * sb + t] = wk - s;
 }
 
-// backward, node i eliminated at stride h (or the last node): x_i = Linv_i^T (y_i - U_i x_{i-h} - V_i x_{i+h})
-__global__ __launch_bounds__(256) void cr_bwd_kernel(const CrView v, const uint32_t h, const int final_node, double* __restrict__ w,
-                                                     const double* __restrict__ done_flag)
+// backward, node i eliminated at stride h (or the last node): x_i = E_i w_i - P_i x_{i-h} - Q_i x_{i+h}
+__global__ __launch_bounds__(kCrSolveThreads) void cr_bwd_kernel(const CrView v, const uint32_t h, const int final_node,
+                                                                 double* __restrict__ w, const double* __restrict__ done_flag)
 {
-    __shared__ double tl[64];
-    __shared__ double red[4][64];
+    __shared__ double red[kCrSolveGroups][64];
     if (cr_done(done_flag)) return;
-    const int sb = v.sb, t = threadIdx.x % 64, g = threadIdx.x / 64;
+    const int sb = v.sb, t = threadIdx.x % 64, g = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
     const size_t sb2 = (size_t)sb * sb;
     const uint32_t i = final_node ? 0u : h * (2 * blockIdx.x + 1);
     if (i >= v.m) return;
-    double s = 0.0;
-    if (t < sb) {
-        if (!final_node && i >= h) {
-            const double* M = v.U + i * sb2 + (size_t)t * sb;
-            const double* x = w + (size_t)(i - h) * sb;
-            for (int m = g; m < sb; m += 4) s += M[m] * x[m];
-        }
-        if (!final_node && i + h < v.m) {
-            const double* M = v.V + i * sb2 + (size_t)t * sb;
-            const double* x = w + (size_t)(i + h) * sb;
-            for (int m = g; m < sb; m += 4) s += M[m] * x[m];
-        }
-    }
-    s = quarter_sum(s, red, t, g);
-    if (g == 0 && t < sb) tl[t] = w[(size_t)i * sb + t] - s;
-    __syncthreads();
-    double u = 0.0;
-    if (t < sb) {
-        const double* M = v.Linv + i * sb2 + t;   // column t of Linv, rows t..sb-1
-        for (int k = t + g; k < sb; k += 4) u += M[(size_t)k * sb] * tl[k];
-    }
-    u = quarter_sum(u, red, t, g);
-    if (g == 0 && t < sb) w[(size_t)i * sb + t] = u;
+    const bool has_a = !final_node && i >= h, has_c = !final_node && i + h < v.m;
+    const uint32_t a = has_a ? i - h : 0, c = has_c ? i + h : 0;
+    ColOp oe, oa, oc;
+    col_load(oe, v.E + i * sb2, w + (size_t)i * sb, sb, t, g, true);   // E symmetric
+    col_load(oa, v.PT + i * sb2, w + (size_t)a * sb, sb, t, g, has_a);
+    col_load(oc, v.QT + i * sb2, w + (size_t)c * sb, sb, t, g, has_c);
+    const double s = group_sum(col_dot(oe) - col_dot(oa) - col_dot(oc), red, t, g);
+    if (g == 0 && t < sb) w[(size_t)i * sb + t] = s;
 }
 
 __global__ __launch_bounds__(256) void cr_load_rhs_kernel(uint32_t n, uint32_t n_pad, const double* __restrict__ b, double* __restrict__ w,
@@ -419,13 +440,15 @@ __global__ __launch_bounds__(256) void cr_store_x_kernel(uint32_t n, const doubl
     if (i < n) x[i] = w[i];
 }
 
+constexpr int kCrMats = 7;
+
 CrView make_view(uint32_t n_rows, int bw, double* ws)
 {
     CrView v;
     v.bw = bw; v.sb = 6 * bw;
     v.m = (n_rows + (uint32_t)bw - 1) / (uint32_t)bw;
     const size_t per = (size_t)v.m * v.sb * v.sb;
-    v.D = ws; v.F = ws + per; v.Linv = ws + 2 * per; v.U = ws + 3 * per; v.V = ws + 4 * per;
+    v.D = ws; v.F = ws + per; v.E = ws + 2 * per; v.P = ws + 3 * per; v.Q = ws + 4 * per; v.PT = ws + 5 * per; v.QT = ws + 6 * per;
     return v;
 }
 
@@ -437,7 +460,7 @@ uint32_t count_even(uint32_t m, uint32_t h) { return (m + 2 * h - 1) / (2 * h); 
 size_t cr_count(uint32_t n_rows, int bw)
 {
     const size_t m = (n_rows + (size_t)bw - 1) / (size_t)bw, sb = 6 * (size_t)bw;
-    return 5 * m * sb * sb + m * sb + 64;   // D F Linv U V + padded work vector
+    return kCrMats * m * sb * sb + m * sb + 64;   // D F E P Q PT QT + padded work vector
 }
 
 void launch_cr_factor(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, int bw,
@@ -450,33 +473,30 @@ void launch_cr_factor(hipStream_t s, const BsrView& A, uint32_t n_blocks, const 
     const uint32_t pad = v.m * (uint32_t)bw - A.n_rows;
     hipLaunchKernelGGL(cr_assemble_kernel, dim3(n_blocks + pad), dim3(64), 0, s, A.blocks, blk_row, blk_col, n_blocks, A.n_rows, v);
     const size_t kp = ((size_t)v.sb + 3) & ~(size_t)3;
-    const size_t lds_f = sizeof(double) * (2 * (size_t)v.sb * v.sb + 2 * kp * kLd + 2 * (size_t)bw * 36);
-    const size_t lds_u = sizeof(double) * 2 * kp * kLd;
-    if (lds_f > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-    if (lds_u > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_u);
+    const size_t lds_i = sizeof(double) * ((size_t)v.sb * (v.sb | 1) + 2 * 192);
+    const size_t lds_r = sizeof(double) * 4 * kp * kLd;
+    if (lds_i > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_invert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_i);
+    if (lds_r > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+    const uint32_t nt = ((uint32_t)v.sb + 15) / 16;
     for (uint32_t h = 1; h < v.m; h *= 2) {
-        hipLaunchKernelGGL(cr_factor_kernel, dim3(count_odd(v.m, h)), dim3(kCrThreads), lds_f, s, v, h, 0, scal);
-        hipLaunchKernelGGL(cr_update_kernel, dim3(count_even(v.m, h)), dim3(kCrThreads), lds_u, s, v, h);
+        hipLaunchKernelGGL(cr_invert_kernel, dim3(count_odd(v.m, h)), dim3(64 * bw), lds_i, s, v, h, 0, scal);
+        hipLaunchKernelGGL(cr_reduce_kernel, dim3(count_even(v.m, h), nt), dim3(kCrReduceThreads), lds_r, s, v, h);
     }
-    hipLaunchKernelGGL(cr_factor_kernel, dim3(1), dim3(kCrThreads), lds_f, s, v, 0u, 1, scal);
+    hipLaunchKernelGGL(cr_invert_kernel, dim3(1), dim3(64 * bw), lds_i, s, v, 0u, 1, scal);
 }
 
 void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const double* b, double* x, const double* done_flag)
 {
     if (!n_rows) return;
     const CrView v = make_view(n_rows, bw, ws);
-    double* w = ws + 5 * (size_t)v.m * v.sb * v.sb;
+    double* w = ws + kCrMats * (size_t)v.m * v.sb * v.sb;
     const uint32_t n = n_rows * 6, n_pad = v.m * (uint32_t)v.sb;
     hipLaunchKernelGGL(cr_load_rhs_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, n, n_pad, b, w, done_flag);
     uint32_t h = 1;
-    for (; h < v.m; h *= 2) {
-        hipLaunchKernelGGL(cr_fwd_kernel, dim3(count_odd(v.m, h)), dim3(256), 0, s, v, h, 0, w, done_flag);
-        hipLaunchKernelGGL(cr_fwd_update_kernel, dim3(count_even(v.m, h)), dim3(256), 0, s, v, h, w, done_flag);
-    }
-    hipLaunchKernelGGL(cr_fwd_kernel, dim3(1), dim3(256), 0, s, v, 0u, 1, w, done_flag);
-    hipLaunchKernelGGL(cr_bwd_kernel, dim3(1), dim3(256), 0, s, v, 0u, 1, w, done_flag);
+    for (; h < v.m; h *= 2) hipLaunchKernelGGL(cr_fwd_kernel, dim3(count_even(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, w, done_flag);
+    hipLaunchKernelGGL(cr_bwd_kernel, dim3(1), dim3(kCrSolveThreads), 0, s, v, 0u, 1, w, done_flag);
     for (h /= 2; h >= 1; h /= 2) {
-        hipLaunchKernelGGL(cr_bwd_kernel, dim3(count_odd(v.m, h)), dim3(256), 0, s, v, h, 0, w, done_flag);
+        hipLaunchKernelGGL(cr_bwd_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, 0, w, done_flag);
         if (h == 1) break;
     }
     hipLaunchKernelGGL(cr_store_x_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, w, x, done_flag);
