@@ -46,6 +46,14 @@ struct SchurBatch {
     uint32_t q_begin, q_end;  // point-major observation positions
     uint32_t p_begin, p_end;  // internal point range
 };
+// A point seen by more free cameras than the widest Schur window (32), or with more observations than a batch
+// holds, is eliminated by the long-track kernels: its W / Y blocks go to a scratch array and one 36-lane group per
+// camera pair writes that pair's product to the slab.
+struct LongPoint {
+    uint32_t p;                 // internal point
+    uint32_t lo_begin, lo_end;  // its free-camera observations in the long-observation arrays
+    uint32_t pad;
+};
 
 struct LmDiag {     // what a kernel needs to rebuild the point damping
     double radius, lo, hi;
@@ -79,6 +87,13 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
                   const uint32_t* chunk_slab, const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* jc,
                   const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* slab,
                   double* scal);
+
+// long-track points (see LongPoint): damped point block inverse, W / Y of every free-camera observation into
+// wy[lo][36] and Y g into the slab at lo_cam_off[lo]; then Y_a W_b^T of every listed pair into the slab at pair_off
+void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts, const uint32_t* lo_row, const uint32_t* lo_cam_off,
+                       uint32_t n_pairs, const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* pair_off, const double* jc,
+                       const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* wy,
+                       double* slab, double* scal);
 
 // S = B - sum(slabs), rhs = -g_c + sum(slab rhs parts) through host-built contribution lists (fixed order);
 // exports diag(B) and g_c next to them for the all-reduce

@@ -516,6 +516,71 @@ __global__ __launch_bounds__(NT) void ba_schur_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Long tracks: points outside the windowed kernel's limits (more than 32 free cameras or more than kBatchObs
+// observations - a landmark watched while the vehicle stands still).  Same arithmetic, no window: W and Y of
+// every observation go to a scratch array, then one 36-lane group per camera pair (host-built list, fixed order)
+// writes Y_a W_b^T to that pair's own slab slot.  No atomics; ba_schur_reduce adds the slots like any chunk's.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ba_long_prepare_kernel(const LongPoint* __restrict__ long_pts, const uint32_t* __restrict__ lo_row,
+                                                             const uint32_t* __restrict__ lo_cam_off, const double* __restrict__ jc,
+                                                             const double* __restrict__ jpr, const double* __restrict__ C,
+                                                             const double* __restrict__ gp, const double* __restrict__ sp,
+                                                             const LmDiag lm, double* __restrict__ Cinv, double* __restrict__ wy,
+                                                             double* __restrict__ slab, double* __restrict__ scal)
+{
+    const LongPoint lp = long_pts[blockIdx.x];
+    const size_t p = lp.p;
+    double m[6], ci[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) m[i] = C[6 * p + i];
+    m[0] += point_lambda(m[0], sp[3 * p], lm);
+    m[3] += point_lambda(m[3], sp[3 * p + 1], lm);
+    m[5] += point_lambda(m[5], sp[3 * p + 2], lm);
+    const bool ok = sym3_inverse(m, ci);
+    if (threadIdx.x == 0) {
+        if (!ok) scal[SC_SCHUR_STATUS] = 1.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) Cinv[6 * p + i] = ci[i];
+    }
+    const double g0 = gp[3 * p], g1 = gp[3 * p + 1], g2 = gp[3 * p + 2];
+    for (uint32_t lo = lp.lo_begin + threadIdx.x; lo < lp.lo_end; lo += 64) {
+        const size_t q = lo_row[lo];
+        const double* a = jc + kJcRow * q;     // 4x6 row-major
+        const double* b = jpr + kJprRow * q;   // 4x3 row-major, then the residual
+        double bb[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) bb[i] = b[i];
+        double* out = wy + 36 * (size_t)lo;
+        double* cam = slab + lo_cam_off[lo];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const double a0 = a[r], a1 = a[6 + r], a2 = a[12 + r], a3 = a[18 + r];
+            const double w0 = a0 * bb[0] + a1 * bb[3] + a2 * bb[6] + a3 * bb[9];
+            const double w1 = a0 * bb[1] + a1 * bb[4] + a2 * bb[7] + a3 * bb[10];
+            const double w2 = a0 * bb[2] + a1 * bb[5] + a2 * bb[8] + a3 * bb[11];
+            const double y0 = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
+            const double y1 = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
+            const double y2 = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
+            out[r * 3] = w0; out[r * 3 + 1] = w1; out[r * 3 + 2] = w2;
+            out[18 + r * 3] = y0; out[18 + r * 3 + 1] = y1; out[18 + r * 3 + 2] = y2;
+            cam[r] = y0 * g0 + y1 * g1 + y2 * g2;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ba_long_pairs_kernel(uint32_t n_pairs, const uint32_t* __restrict__ pair_a,
+                                                            const uint32_t* __restrict__ pair_b, const uint32_t* __restrict__ pair_off,
+                                                            const double* __restrict__ wy, double* __restrict__ slab)
+{
+    const int t = threadIdx.x % 36;
+    const uint32_t pair = blockIdx.x * 7 + threadIdx.x / 36;
+    if (threadIdx.x >= 252 || pair >= n_pairs) return;
+    const double* Y = wy + 36 * (size_t)pair_a[pair] + 18 + (t / 6) * 3;
+    const double* W = wy + 36 * (size_t)pair_b[pair] + (t % 6) * 3;
+    slab[pair_off[pair] + t] = Y[0] * W[0] + Y[1] * W[1] + Y[2] * W[2];
+}
+
 // S = B (diagonal blocks) - sum of the chunk windows, rhs = -g_c + sum of the chunk rhs parts, in the fixed
 // order of the host-built contribution lists; also exports diag(B) and g_c for the all-reduce.  Overwrites
 // S and rhs completely (no memset needed).
@@ -745,6 +810,18 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
     else
         hipLaunchKernelGGL((ba_schur_kernel<32, 576>), dim3(n_chunks), dim3(576), 0, s, chunks, batches, chunk_slab, pt_obs, q_pt, q_slot,
                            jc, jpr, C, gp, sp, lm, Cinv, slab, scal);
+}
+
+void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts, const uint32_t* lo_row, const uint32_t* lo_cam_off,
+                       uint32_t n_pairs, const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* pair_off, const double* jc,
+                       const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* wy,
+                       double* slab, double* scal)
+{
+    if (!n_long) return;
+    hipLaunchKernelGGL(ba_long_prepare_kernel, dim3(n_long), dim3(64), 0, s, long_pts, lo_row, lo_cam_off, jc, jpr, C, gp, sp, lm, Cinv,
+                       wy, slab, scal);
+    if (n_pairs)
+        hipLaunchKernelGGL(ba_long_pairs_kernel, dim3((n_pairs + 6) / 7), dim3(256), 0, s, n_pairs, pair_a, pair_b, pair_off, wy, slab);
 }
 
 void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, const uint32_t* blk_ptr, const uint32_t* blk_off,

@@ -83,6 +83,11 @@ struct soslam_ba {
     DevBuf<double> slab;
     DevBuf<SchurChunk> chunks;
     DevBuf<SchurBatch> batches;
+    // long-track points (beyond the Schur window / batch limits)
+    DevBuf<LongPoint> long_pts;
+    DevBuf<uint32_t> lo_row, lo_cam_off, pair_a, pair_b, pair_off;
+    DevBuf<double> long_wy;
+    uint32_t n_long = 0, n_long_pairs = 0, n_short = 0;
     DevBuf<uint32_t> row_ptr, ent_col, ent_blk, blk_row, blk_col;
 
     // state and work buffers
@@ -197,19 +202,24 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
 
     // internal point order: by (first camera, last camera, caller id) so that neighbouring points share
     // their camera window (the Schur kernel's chunks) and a camera bucket reads near-contiguous points
-    std::vector<uint32_t> pmin(n_pt, UINT32_MAX), pmax(n_pt, 0), pcnt(n_pt, 0);
+    std::vector<uint32_t> pmin(n_pt, UINT32_MAX), pmax(n_pt, 0), pcnt(n_pt, 0), pfree(n_pt, 0);
     for (uint32_t k = 0; k < n_obs; k++) {
         const uint32_t p = opt_[k], c = ocam[k];
         pmin[p] = std::min(pmin[p], c); pmax[p] = std::max(pmax[p], c); pcnt[p]++;
+        if (h->h_cam_free[c] >= 0) pfree[p]++;
     }
+    // long tracks (more free cameras than the widest Schur window, or more observations than a batch) go last
+    // and are eliminated by the long-track kernels
+    constexpr uint32_t kWindowMax = 32;
+    std::vector<uint8_t> is_long(n_pt, 0);
+    uint32_t n_long = 0;
     for (uint32_t p = 0; p < n_pt; p++)
-        if (pcnt[p] > (uint32_t)kBatchObs) {
-            set_last_error("point %u has %u observations; this build supports up to %d per point", p, pcnt[p], kBatchObs);
-            return SOSLAM_ERR_INVALID_ARGUMENT;
-        }
+        if (pfree[p] > kWindowMax || pcnt[p] > (uint32_t)kBatchObs) { is_long[p] = 1; n_long++; }
+    const uint32_t n_short = n_pt - n_long;
     h->pt_int2user.resize(n_pt);
     std::iota(h->pt_int2user.begin(), h->pt_int2user.end(), 0u);
     std::sort(h->pt_int2user.begin(), h->pt_int2user.end(), [&](uint32_t a, uint32_t b) {
+        if (is_long[a] != is_long[b]) return is_long[a] < is_long[b];
         if (pmin[a] != pmin[b]) return pmin[a] < pmin[b];
         if (pmax[a] != pmax[b]) return pmax[a] < pmax[b];
         return a < b;
@@ -275,7 +285,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                 const int32_t f = h->h_cam_free[v_obs_cam[pt_obs[q]]];
                 if (f >= 0 && (fc.empty() || fc.back() != (uint32_t)f)) fc.push_back((uint32_t)f);
             }
-            max_track = std::max<uint32_t>(max_track, (uint32_t)fc.size());
+            if (p < n_short) max_track = std::max<uint32_t>(max_track, (uint32_t)fc.size());
             for (size_t a = 0; a < fc.size(); a++)
                 for (size_t b = a + 1; b < fc.size(); b++) rows[fc[a]].push_back(fc[b]);
         }
@@ -292,10 +302,6 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             std::sort(r.begin(), r.end());
             r.erase(std::unique(r.begin(), r.end()), r.end());
         }
-    }
-    if (max_track > 32) {
-        set_last_error("a point is observed by %u free cameras; this build supports tracks up to 32", max_track);
-        return SOSLAM_ERR_INVALID_ARGUMENT;
     }
     h->kmax = max_track > 16 ? 32 : 16;
     std::vector<uint32_t> row_first(nf + 1, 0);
@@ -387,7 +393,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             chunk_p0 = p_end;
             local.clear();
         };
-        for (uint32_t p = 0; p < n_pt; p++) {
+        for (uint32_t p = 0; p < n_short; p++) {
             fc.clear();
             for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
                 const int32_t f = h->h_cam_free[v_obs_cam[pt_obs[q]]];
@@ -401,8 +407,52 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             }
             local = merged;
         }
-        close_chunk(n_pt);
+        close_chunk(n_short);
     }
+    // long-track points: one slab slot per camera pair and per camera, through the same contribution lists
+    std::vector<LongPoint> long_pts;
+    std::vector<uint32_t> lo_row, lo_cam_off, pair_a, pair_b, pair_off;
+    {
+        std::vector<uint32_t> lf;   // free camera of each long observation of the current point
+        for (uint32_t p = n_short; p < n_pt; p++) {
+            LongPoint lp{p, (uint32_t)lo_row.size(), 0, 0};
+            lf.clear();
+            for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
+                const int32_t f = h->h_cam_free[v_obs_cam[pt_obs[q]]];
+                if (f < 0) continue;
+                if (!lf.empty() && lf.back() == (uint32_t)f) {
+                    set_last_error("point %u is observed twice by camera %u", h->pt_int2user[p], v_obs_cam[pt_obs[q]]);
+                    return SOSLAM_ERR_INVALID_ARGUMENT;
+                }
+                lf.push_back((uint32_t)f);
+                lo_row.push_back(pt_obs[q]);
+            }
+            lp.lo_end = (uint32_t)lo_row.size();
+            const size_t k = lf.size();
+            if (slab_count + (uint64_t)k * (k + 1) / 2 * 36 + (uint64_t)k * 6 > 0xFFFFFFF0ull) {
+                set_last_error("Schur slab exceeds 32-bit offsets");
+                return SOSLAM_ERR_INVALID_ARGUMENT;
+            }
+            for (size_t a = 0; a < k; a++)
+                for (size_t b = a; b < k; b++) {
+                    const int32_t blk = find_block(lf[a], lf[b]);
+                    pair_a.push_back(lp.lo_begin + (uint32_t)a);
+                    pair_b.push_back(lp.lo_begin + (uint32_t)b);
+                    pair_off.push_back((uint32_t)slab_count);
+                    if (blk >= 0) blk_contrib[(size_t)blk].push_back((uint32_t)slab_count);
+                    slab_count += 36;
+                }
+            for (size_t a = 0; a < k; a++) {
+                lo_cam_off.push_back((uint32_t)slab_count);
+                cam_contrib[lf[a]].push_back((uint32_t)slab_count);
+                slab_count += 6;
+            }
+            long_pts.push_back(lp);
+        }
+    }
+    h->n_long = (uint32_t)long_pts.size();
+    h->n_long_pairs = (uint32_t)pair_a.size();
+    h->n_short = n_short;
     if (slab_count > 0xFFFFFFF0ull) { set_last_error("Schur slab exceeds 32-bit offsets"); return SOSLAM_ERR_INVALID_ARGUMENT; }
     std::vector<uint32_t> bc_ptr(h->n_blocks + 1, 0), bc_off, cc_ptr(nf + 1, 0), cc_off;
     for (uint32_t b = 0; b < h->n_blocks; b++) {
@@ -445,6 +495,13 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->chunks.upload(chunks, s));
     SOSLAM_CHECK(h->batches.upload(batches, s));
     SOSLAM_CHECK(h->chunk_slab.upload(chunk_slab, s));
+    SOSLAM_CHECK(h->long_pts.upload(long_pts, s));
+    SOSLAM_CHECK(h->lo_row.upload(lo_row, s));
+    SOSLAM_CHECK(h->lo_cam_off.upload(lo_cam_off, s));
+    SOSLAM_CHECK(h->pair_a.upload(pair_a, s));
+    SOSLAM_CHECK(h->pair_b.upload(pair_b, s));
+    SOSLAM_CHECK(h->pair_off.upload(pair_off, s));
+    SOSLAM_CHECK(h->long_wy.alloc(lo_row.size() * 36));
     SOSLAM_CHECK(h->blk_contrib_ptr.upload(bc_ptr, s));
     SOSLAM_CHECK(h->blk_contrib_off.upload(bc_off, s));
     SOSLAM_CHECK(h->cam_contrib_ptr.upload(cc_ptr, s));
@@ -559,6 +616,16 @@ BsrView bsr_view(const soslam_ba* h)
     return BsrView{h->n_free, h->row_ptr.p, h->ent_col.p, h->ent_blk.p, h->ent_trans.p, h->diag_block.p, h->S()};
 }
 
+// point elimination: windowed chunks, then the long-track points; both write slab slots for ba_schur_reduce
+void run_schur(soslam_ba* h, const LmDiag& lm)
+{
+    hipStream_t s = h->stream;
+    launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->pt_obs.p, h->q_pt.p, h->q_slot.p,
+                 h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
+    launch_schur_long(s, h->n_long, h->long_pts.p, h->lo_row.p, h->lo_cam_off.p, h->n_long_pairs, h->pair_a.p, h->pair_b.p,
+                      h->pair_off.p, h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->long_wy.p, h->slab.p, h->scalp());
+}
+
 // one trust-region step from the current linearisation: reduced system, solve, candidate, candidate cost
 int take_step(soslam_ba* h, double radius)
 {
@@ -566,8 +633,7 @@ int take_step(soslam_ba* h, double radius)
     const LmDiag lm = lm_diag(h, radius);
     {
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
-        launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->pt_obs.p, h->q_pt.p, h->q_slot.p,
-                     h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
+        run_schur(h, lm);
         launch_schur_reduce(s, h->n_blocks, h->n_free, h->blk_contrib_ptr.p, h->blk_contrib_off.p, h->cam_contrib_ptr.p,
                             h->cam_contrib_off.p, h->blk_row.p, h->blk_col.p, h->slab.p, h->B.p, h->gc.p, h->S(), h->rhs(),
                             h->diagB(), h->gc_red());
@@ -1058,8 +1124,7 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
     if (kernel < 0 || kernel > SOSLAM_KERNEL_BACKSUB) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return SOSLAM_ERR_INVALID_ARGUMENT; }
     if (kernel == SOSLAM_KERNEL_BACKSUB) {
         SOSLAM_HIP_CHECK(hipMemsetAsync(h->dc_full.p, 0, sizeof(double) * 6 * h->n_cam, s));
-        launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->pt_obs.p, h->q_pt.p, h->q_slot.p,
-                     h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
+        run_schur(h, lm);
     }
     once();  // warm-up
     SOSLAM_HIP_CHECK(hipEventRecord(e0, s));

@@ -390,6 +390,41 @@ def test_band_solver_widths(gpu, oracle_lib, solver, track):
     assert sc[1] == pytest.approx(ref["model_cost_change"], rel=1e-7)
 
 
+def _merge_problems(synth, a, b):
+    """Points of b appended to a (same cameras)."""
+    assert a.n_cam == b.n_cam and np.array_equal(a.poses_wc, b.poses_wc)
+    oc = np.concatenate([a.obs_cam, b.obs_cam])
+    op = np.concatenate([a.obs_pt, b.obs_pt + np.uint32(a.n_pt)])
+    uv = np.concatenate([a.obs_uv, b.obs_uv])
+    order = np.lexsort((op, oc))
+    return synth.BaProblem(a.poses_wc, np.concatenate([a.points, b.points]), oc[order], op[order], uv[order], a.proj_l, a.proj_r)
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_tracks_longer_than_the_window(gpu, oracle_lib, solver):
+    """A landmark watched from more than 32 free cameras (a vehicle standing still) does not fit the windowed Schur
+    kernel; the long-track kernels eliminate it through the same slab lists.  800 ordinary points plus 14 points
+    seen by 60 consecutive cameras of a 70-camera chain."""
+    ba, synth, L = gpu
+    a = synth.generate_ba(None, n_cam=70, n_pt=800, track_mode=0, track_len=6, spacing=0.05)
+    b = synth.generate_ba(None, n_cam=70, n_pt=14, track_mode=0, track_len=60, spacing=0.05)
+    q = _merge_problems(synth, a, b)
+    assert np.bincount(q.obs_pt).max() == 60
+    ref = oracle_lib.step(q.obs_cam, q.obs_pt, q.obs_uv, q.poses_cw(), q.points_f64(), q.proj_l, q.proj_r, q.cam_fixed, 1e3)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=solver, pcg_tolerance=1e-13, pcg_max_iterations=3000)) as h:
+        h.load(q)
+        h.debug_step(1e3)
+        S, dc, dp = h.debug_read(L.DBG_S_DENSE), h.debug_read(L.DBG_STEP_CAM), h.debug_read(L.DBG_STEP_POINT)
+    np.testing.assert_allclose(S, ref["S"], rtol=1e-9, atol=1e-11 * np.abs(ref["S"]).max())
+    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-4, atol=1e-6 * np.abs(ref["dc"]).max())
+    np.testing.assert_allclose(dp, ref["dp"], rtol=1e-4, atol=1e-6 * np.abs(ref["dp"]).max())
+    # and a full solve against the oracle
+    cams, pts, summ = ba.optimize(q, ba.default_options(max_iterations=8, linear_solver=solver, pcg_tolerance=1e-12,
+                                                        pcg_max_iterations=3000))
+    ocams, opts_, osum, _ = _oracle_solve(oracle_lib, q, max_iterations=8)
+    _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+
+
 def test_long_tracks_use_the_wide_window(gpu, oracle_lib):
     """Tracks of 24 cameras select the 32-slot Schur window."""
     ba, synth, L = gpu
