@@ -145,6 +145,10 @@ void soslam_ba_options_default(soslam_ba_options* opts);
 
 int  soslam_ba_create(const soslam_ba_options* opts, soslam_ba** out);
 void soslam_ba_destroy(soslam_ba* h);
+/* Replace the options of a live handle (device and stream stay).  A handle kept across calls - one window after
+ * another, /root/reference/src/slam.cpp:121-129 - re-uses its device allocations; changing linear_solver takes
+ * effect at the next set_problem. */
+int  soslam_ba_set_options(soslam_ba* h, const soslam_ba_options* opts);
 
 /* Replaces ReprojectionError::SetLeftProjection / SetRightProjection
  * (/root/reference/src/reprojection_error.h:43-51): explicit problem data instead of process globals. */

@@ -82,7 +82,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int3
 # every symbol include/*.h declares; tests/test_cabi.py checks the library exports each one
 BA_SYMBOLS = [
     "soslam_version", "soslam_status_string", "soslam_last_error", "soslam_ba_options_default", "soslam_ba_create",
-    "soslam_ba_destroy", "soslam_ba_set_projection", "soslam_ba_set_problem", "soslam_ba_set_state",
+    "soslam_ba_destroy", "soslam_ba_set_options", "soslam_ba_set_projection", "soslam_ba_set_problem", "soslam_ba_set_state",
     "soslam_ba_get_state", "soslam_ba_solve", "soslam_ba_iterate", "soslam_ba_get_iteration_log",
     "soslam_ba_optimize", "soslam_ba_set_covisibility", "soslam_ba_set_allreduce", "soslam_ba_reduce_buffer_count", "soslam_ba_set_reduce_buffer",
     "soslam_ba_shard_range", "soslam_ba_time_kernel", "soslam_ba_debug_step", "soslam_ba_debug_read",
@@ -118,12 +118,28 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _pin_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel carries its own libamdhip64.so (SONAME libamdhip64.so.7) and
+    asks for it by FILE name, so a process that loads libsoslam_ba.so first (system runtime, by SONAME) and torch
+    afterwards ends up with two runtimes, and the second one to initialise sees no device.  Loading torch's copy
+    first makes both requests resolve to the same object, whatever the import order.  Without torch installed
+    nothing is preloaded and the system runtime is used, as in a C++ host."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no fallback implementation)")
+    _pin_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, u64, dbl = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_double
     L.soslam_version.restype = C.c_char_p
@@ -133,6 +149,7 @@ def lib():
     L.soslam_ba_options_default.argtypes = [C.POINTER(BaOptions)]
     L.soslam_ba_options_default.restype = None
     L.soslam_ba_create.argtypes = [C.POINTER(BaOptions), C.POINTER(vp)]
+    L.soslam_ba_set_options.argtypes = [vp, C.POINTER(BaOptions)]
     L.soslam_ba_destroy.argtypes = [vp]
     L.soslam_ba_destroy.restype = None
     L.soslam_ba_set_projection.argtypes = [vp, vp, vp]

@@ -41,6 +41,11 @@ class BundleAdjustment:
         self._keep = []
         self.n_cam = self.n_pt = self.n_obs = self.n_free = 0
 
+    def set_options(self, options):
+        """Replace the options of the live handle (device and stream stay)."""
+        _lib.check(self._L.soslam_ba_set_options(self._h, C.byref(options)), "soslam_ba_set_options")
+        self.options = options
+
     def close(self):
         if self._h:
             self._L.soslam_ba_destroy(self._h)

@@ -937,6 +937,22 @@ int soslam_ba_create(const soslam_ba_options* opts, soslam_ba** out)
     return SOSLAM_OK;
 }
 
+int soslam_ba_set_options(soslam_ba* h, const soslam_ba_options* opts)
+{
+    if (!h || !opts) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if ((opts->device >= 0 && opts->device != h->device) || (opts->stream && opts->stream != h->opt.stream)) {
+        set_last_error("set_options cannot move a handle to another device or stream");
+        return SOSLAM_ERR_INVALID_ARGUMENT;
+    }
+    void* const stream = h->opt.stream;
+    const int32_t device = h->opt.device;
+    h->opt = *opts;
+    h->opt.stream = stream;
+    h->opt.device = device;
+    h->linearized = false;   // the linear solver was chosen (and its work space sized) in set_problem and stays
+    return SOSLAM_OK;
+}
+
 void soslam_ba_destroy(soslam_ba* h)
 {
     if (!h) return;

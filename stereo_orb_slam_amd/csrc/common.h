@@ -31,11 +31,14 @@ void set_last_error(const char* fmt, ...);
         if (_s != SOSLAM_OK) return _s;      \
     } while (0)
 
-// Device allocation owned by a handle.  No copies, freed in the destructor.
+// Device allocation owned by a handle.  No copies, freed in the destructor.  alloc() keeps an existing allocation that
+// is large enough: a handle that is given one window after another (the reference's per-frame / sliding-window
+// schedule) stops calling hipMalloc once it has seen its largest window.
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
-    size_t n = 0;
+    size_t n = 0;     // elements in use
+    size_t cap = 0;   // elements allocated
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -45,13 +48,17 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        cap = 0;
     }
     int alloc(size_t count)
     {
+        if (p && cap >= count) { n = count; return SOSLAM_OK; }
         release();
+        size_t want = count + count / 4;   // head room: consecutive windows differ by a few percent
+        if (want == 0) want = 1;
+        SOSLAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
         n = count;
-        if (count == 0) count = 1;
-        SOSLAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        cap = want;
         return SOSLAM_OK;
     }
     int upload(const std::vector<T>& h, hipStream_t s)

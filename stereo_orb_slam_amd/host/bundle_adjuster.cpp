@@ -30,6 +30,8 @@ BundleAdjuster::BundleAdjuster(std::vector<Frame*>& cam_frames, std::vector<MapP
     m_options.max_solver_time_seconds = 0.0;    // set to BA_MAX_TIME_SEC for the stock wall-clock cap (:18)
 }
 
+BundleAdjuster::~BundleAdjuster() { soslam_ba_destroy(m_handle); }
+
 void BundleAdjuster::Optimize(unsigned int start_frame_id, unsigned int end_frame_id)
 {
     m_status = SOSLAM_OK;
@@ -70,9 +72,16 @@ void BundleAdjuster::Optimize(unsigned int start_frame_id, unsigned int end_fram
     std::vector<uint8_t> fixed(n_cam, 0);
     fixed[0] = 1;
 
-    m_status = soslam_ba_optimize(&m_options, ReprojectionError::p_l.data(), ReprojectionError::p_r.data(), n_cam, poses.data(),
-                                  (uint32_t)point_ids.size(), points.data(), (uint32_t)obs_cam.size(), obs_cam.data(),
-                                  obs_pt.data(), obs_uv.data(), fixed.data(), &m_summary);
+    // create / upload / solve / download on the adjuster's own handle; poses and points are local copies, so the map
+    // is only touched after every step has succeeded
+    m_status = m_handle ? soslam_ba_set_options(m_handle, &m_options) : soslam_ba_create(&m_options, &m_handle);
+    if (m_status == SOSLAM_OK) m_status = soslam_ba_set_projection(m_handle, ReprojectionError::p_l.data(), ReprojectionError::p_r.data());
+    if (m_status == SOSLAM_OK)
+        m_status = soslam_ba_set_problem(m_handle, n_cam, (uint32_t)point_ids.size(), (uint32_t)obs_cam.size(), obs_cam.data(),
+                                         obs_pt.data(), obs_uv.data(), fixed.data());
+    if (m_status == SOSLAM_OK) m_status = soslam_ba_set_state(m_handle, poses.data(), points.data());
+    if (m_status == SOSLAM_OK) m_status = soslam_ba_solve(m_handle, &m_summary);
+    if (m_status == SOSLAM_OK) m_status = soslam_ba_get_state(m_handle, poses.data(), points.data());
     if (m_status != SOSLAM_OK) {
         // the caller's map state is left untouched on failure (failure handling)
         std::fprintf(stderr, "[FAIL]: bundle adjustment failed: %s (%s)\n", soslam_status_string(m_status), soslam_last_error());

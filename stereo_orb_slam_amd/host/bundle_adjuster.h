@@ -1,6 +1,8 @@
 // bundle_adjuster.h - host shim with the reference's entry point
 //   BundleAdjuster(std::vector<Frame*>&, std::vector<MapPoint*>&); void Optimize(unsigned start, unsigned end);
-// (/root/reference/src/bundle_adjuster.h:13-25).  Everything ceres::Solve did is behind soslam_ba_optimize.
+// (/root/reference/src/bundle_adjuster.h:13-25).  Everything ceres::Solve did is behind the C ABI.  The device handle
+// lives as long as the adjuster: the per-frame and sliding-window calls of /root/reference/src/slam.cpp:121-129 reuse
+// its stream and device allocations instead of creating them once per call.
 #pragma once
 
 #include <vector>
@@ -13,6 +15,9 @@
 class BundleAdjuster {
 public:
     BundleAdjuster(std::vector<Frame*>& cam_frames, std::vector<MapPoint*>& ldm_points);
+    ~BundleAdjuster();
+    BundleAdjuster(const BundleAdjuster&) = delete;
+    BundleAdjuster& operator=(const BundleAdjuster&) = delete;
 
     // window [start_frame_id, end_frame_id): first pose of the window constant, every observed point free
     void Optimize(unsigned int start_frame_id, unsigned int end_frame_id);
@@ -28,4 +33,5 @@ private:
     soslam_ba_options m_options;
     soslam_ba_summary m_summary{};
     int m_status = 0;
+    soslam_ba* m_handle = nullptr;   // created by the first Optimize()
 };

@@ -425,6 +425,31 @@ def test_tracks_longer_than_the_window(gpu, oracle_lib, solver):
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
 
 
+def test_a_kept_handle_gives_the_same_answers(gpu, prob1):
+    """The reference runs BA once per frame and once per sliding window (slam.cpp:121-129).  A handle that is given one
+    window after another re-uses its device allocations (grow-only buffers); results must be bitwise those of a fresh
+    handle, whatever was loaded before - larger, smaller, with or without long tracks."""
+    ba, synth, L = gpu
+    small = synth.generate_ba(None, n_cam=1, n_pt=300, track_mode=0, track_len=1)
+    window = synth.generate_ba(None, n_cam=20, n_pt=3000, track_mode=1, track_len=6)
+    wide = synth.generate_ba(None, n_cam=40, n_pt=600, track_mode=0, track_len=36, spacing=0.05)
+    seq = [window, small, prob1, wide, small, window]
+    o = ba.default_options(max_iterations=6)
+    fresh = [ba.optimize(q, o) for q in seq]
+    with ba.BundleAdjustment(o) as h:
+        for q, (cams, pts, summ) in zip(seq, fresh):
+            h.load(q)
+            s2 = h.solve()
+            c2, p2 = h.get_state()
+            assert s2.final_cost == summ.final_cost and s2.iterations == summ.iterations
+            assert np.array_equal(c2, cams) and np.array_equal(p2, pts)
+        # options can change between windows
+        o2 = ba.default_options(max_iterations=2)
+        h.set_options(o2)
+        h.load(prob1)
+        assert h.solve().iterations == 2
+
+
 def test_long_tracks_use_the_wide_window(gpu, oracle_lib):
     """Tracks of 24 cameras select the 32-slot Schur window."""
     ba, synth, L = gpu
