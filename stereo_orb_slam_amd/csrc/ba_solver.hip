@@ -538,7 +538,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->dp.alloc((size_t)n_pt * 3));
     SOSLAM_CHECK(h->part.alloc((size_t)h->n_point_blocks * 5));
     SOSLAM_CHECK(h->lin_resid.alloc((size_t)nf * 6));
-    SOSLAM_CHECK(h->lin_work.alloc(std::max(pcg_work_count(nf), pcg_band_work_count(nf))));
+    SOSLAM_CHECK(h->lin_work.alloc(std::max({pcg_work_count(nf), pcg_band_work_count(nf), pcg_multi_work_count(nf)})));
     SOSLAM_CHECK(h->B.zero(s)); SOSLAM_CHECK(h->gc.zero(s)); SOSLAM_CHECK(h->dc_free.zero(s)); SOSLAM_CHECK(h->Cinv.zero(s));
     SOSLAM_CHECK(h->lin_resid.zero(s));
     if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
@@ -626,6 +626,8 @@ void run_schur(soslam_ba* h, const LmDiag& lm)
                       h->pair_off.p, h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->long_wy.p, h->slab.p, h->scalp());
 }
 
+constexpr uint32_t kPcgMultiMinRows = 64;   // below this one workgroup does a whole PCG iteration faster than three launches
+
 // one trust-region step from the current linearisation: reduced system, solve, candidate, candidate cost
 int take_step(soslam_ba* h, double radius)
 {
@@ -671,6 +673,16 @@ int take_step(soslam_ba* h, double radius)
                 launch_pcg_band(s, bsr_view(h), h->bw, h->band.p, h->bandT.p, h->band_dinv.p, h->rhs(), h->dc_free.p,
                                 h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, 4),
                                 h->scalp());
+                resid = h->lin_resid.p;
+            } else if (h->n_free >= kPcgMultiMinRows) {
+                // no band to factor: block-Jacobi PCG with every vector operation spread over many workgroups
+                double rel = 0.0;
+                const int it = pcg_multi_solve(s, bsr_view(h), 0.0, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
+                                               h->opt.pcg_tolerance, h->opt.pcg_max_iterations, 16, &rel);
+                const double lin[3] = {(double)std::max(it, 0), rel, it < 0 ? 2.0 : 0.0};   // SC_LIN_ITERS, _RESID, _STATUS
+                static_assert(SC_LIN_RESID == SC_LIN_ITERS + 1 && SC_LIN_STATUS == SC_LIN_ITERS + 2, "scalar slots are contiguous");
+                SOSLAM_HIP_CHECK(hipMemcpyAsync(h->scalp() + SC_LIN_ITERS, lin, sizeof lin, hipMemcpyHostToDevice, s));
+                SOSLAM_HIP_CHECK(hipStreamSynchronize(s));   // lin[] lives on this stack frame
                 resid = h->lin_resid.p;
             } else {
                 launch_pcg(s, bsr_view(h), h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance,

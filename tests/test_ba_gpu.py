@@ -425,6 +425,22 @@ def test_tracks_longer_than_the_window(gpu, oracle_lib, solver):
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
 
 
+def test_wide_band_uses_multi_workgroup_pcg(gpu, oracle_lib):
+    """Tracks of 24 cameras over a 150-camera chain: block half-bandwidth 23 is beyond both band factorisations, so
+    PCG runs block-Jacobi preconditioned with every vector operation spread over many workgroups (pcg_multi.hip)."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, n_cam=150, n_pt=6000, track_mode=0, track_len=24, spacing=0.3)
+    ref = oracle_lib.step(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, 1e4)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=2, pcg_tolerance=1e-12, pcg_max_iterations=2000)) as h:
+        h.load(p)
+        h.debug_step(1e4)
+        dc, dp, sc = h.debug_read(L.DBG_STEP_CAM), h.debug_read(L.DBG_STEP_POINT), h.debug_read(L.DBG_STEP_SCALARS)
+    assert sc[5] == 0 and 1 <= sc[4] <= 1000, sc
+    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-5, atol=1e-8 * np.abs(ref["dc"]).max())
+    np.testing.assert_allclose(dp, ref["dp"], rtol=1e-5, atol=1e-8 * np.abs(ref["dp"]).max())
+    assert sc[1] == pytest.approx(ref["model_cost_change"], rel=1e-7)
+
+
 def test_a_kept_handle_gives_the_same_answers(gpu, prob1):
     """The reference runs BA once per frame and once per sliding window (slam.cpp:121-129).  A handle that is given one
     window after another re-uses its device allocations (grow-only buffers); results must be bitwise those of a fresh
