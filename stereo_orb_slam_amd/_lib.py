@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsoslam_ba.so")
+LIB_PATH = os.environ.get("SOSLAM_LIB") or os.path.join(_HERE, "libsoslam_ba.so")   # SOSLAM_LIB: development builds
 CSRC = os.path.join(_HERE, "csrc")
 
 NUM_STAGES = 8

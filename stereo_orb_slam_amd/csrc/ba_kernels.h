@@ -16,7 +16,9 @@ constexpr int kTileVals = 28;        // 21 (J_c^T J_c upper) + 6 (J_c^T r) + 1 (
 constexpr int kJcRow = 24;           // f64 per observation in the J_c array (4x6 row-major, 192 B)
 constexpr int kJprRow = 16;          // f64 per observation in the [J_p | r] array (4x3 row-major + 4, 128 B)
 constexpr int kBatchObs = 128;       // observations staged per Schur batch
-constexpr int kBatchPts = 128;       // points per Schur batch (upper bound)
+// points per Schur batch: the batch's point columns (3 each) are the k dimension of the window GEMM, and two
+// [3 PB][6 KMAX + 1] f64 images must fit LDS next to the staged rows
+constexpr int schur_batch_points(int kmax) { return kmax <= 16 ? 16 : 8; }
 constexpr int kPointBlock = 256;     // threads per block of the per-point kernels
 
 // scalar slots (device f64)

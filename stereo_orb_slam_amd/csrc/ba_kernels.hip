@@ -287,232 +287,289 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_scale_kernel(uint32_t n_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K5  ba_schur: one workgroup per chunk of consecutive points whose cameras fit a window of KMAX local
-// slots.  Per batch (<= 128 observations):
-//   * all lanes fetch the batch's Jacobian rows from HBM as 16-byte pieces - one batch AHEAD, into
-//     registers, so the gather latency hides behind the previous batch's accumulation - and park them in LDS;
-//   * one lane per observation forms W = J_c^T J_p, inverts the damped point block in registers and writes
-//     W, Y = W Cinv to LDS;
-//   * every lane owns a fixed half (3x6) of one local camera-pair block and accumulates Y_a W_b^T over its
-//     share of the batch's points in REGISTERS (no atomics, fixed order).  When the chunk's window needs fewer
-//     lanes than the workgroup has, G lane groups share the items and split the points.
-// The chunk's window goes to its own slab with plain coalesced stores; ba_schur_reduce sums the slabs per
-// block in a fixed order, so the reduced camera system is bitwise reproducible.
+// K5  ba_schur: one workgroup per chunk of consecutive points whose free cameras fit a window of KMAX local
+// slots.  The window's 6 KMAX x 6 KMAX matrix  sum_p Y_p W_p^T  (Y_p, W_p the point's 6 KMAX x 3 column blocks, zero
+// rows for cameras that do not see it) is a GEMM over the concatenated point columns, and it runs on the f64 matrix
+// cores.  Per batch (<= 128 observations, <= PB points):
+//   * all lanes fetch the batch's Jacobian rows from HBM as 16-byte pieces - one batch AHEAD, into registers, so
+//     the gather latency hides behind the previous batch's products - and park them in LDS;
+//   * one lane per point inverts the damped 3x3 block in registers; three lanes per observation form W = J_c^T J_p
+//     and Y = W Cinv and write them into two zero-filled LDS images laid out [point column][window row];
+//   * every wave owns a fixed set of 16x16 tiles of the window's upper triangle and accumulates
+//     v_mfma_f64_16x16x4_f64 products over the batch's columns in registers (no atomics, fixed order); the first
+//     6 KMAX lanes add the rhs part  Y g  with plain FMAs.
+// The chunk's window goes to its own slab ([pair a <= b][6x6] then [camera][6]); ba_schur_reduce sums the slabs
+// per block in a fixed order, so the reduced camera system is bitwise reproducible.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kRawRow = 36;                       // J_c (24) + J_p (12) doubles staged per observation
 constexpr int kRawPieces = kRawRow / 2;           // 16-byte pieces per row
+constexpr int kSchurThreads = 512;
 
-template <int KMAX, int NT>
-__global__ __launch_bounds__(NT) void ba_schur_kernel(
+typedef double schur_double4 __attribute__((ext_vector_type(4)));
+
+template <int KMAX>
+struct SchurShape {
+    static constexpr int PB = schur_batch_points(KMAX);   // points per batch
+    static constexpr int ROWS = 6 * KMAX;                  // window rows
+    static constexpr int LD = ROWS + 1;                    // odd leading dimension of the images
+    static constexpr int KB = 3 * PB;                      // point columns per batch (multiple of 4)
+    static constexpr int NT1 = (ROWS + 15) / 16;           // 16-wide tiles per dimension
+    static constexpr int NUP = NT1 * (NT1 + 1) / 2;        // tiles of the upper triangle
+    static constexpr int TPW = (NUP + kSchurThreads / 64 - 1) / (kSchurThreads / 64);   // tiles per wave
+    static constexpr size_t lds_bytes = sizeof(double) * ((size_t)kBatchObs * kRawRow + 2 * (size_t)KB * LD + 2 * (PB * 6 + KB)) + 2 * kBatchObs;
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load
+// (s_waitcnt vmcnt(0)), which would drain the next batch's prefetch at each barrier; the prefetched registers are
+// guarded by the compiler's own vmcnt bookkeeping at their first use.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
     const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches, const uint32_t* __restrict__ chunk_slab,
     const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_pt, const uint8_t* __restrict__ q_slot, const double* __restrict__ jc,
     const double* __restrict__ jpr, const double* __restrict__ C, const double* __restrict__ gp,
     const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv, double* __restrict__ slab,
     double* __restrict__ scal)
 {
-    constexpr int NPAIR = KMAX * (KMAX + 1) / 2;
-    constexpr int MAX_IPT = (2 * NPAIR + KMAX + NT - 1) / NT;
+    using Sh = SchurShape<KMAX>;
+    constexpr int NT = kSchurThreads, PB = Sh::PB, LD = Sh::LD, KB = Sh::KB, NT1 = Sh::NT1, NUP = Sh::NUP, TPW = Sh::TPW;
     constexpr int PPT = (kBatchObs * kRawPieces + NT - 1) / NT;   // raw pieces per lane
-    static_assert(NT >= kBatchObs && NT >= kBatchPts, "staging needs one lane per batch observation / point");
-    __shared__ __attribute__((aligned(16))) double raw[kBatchObs * kRawRow];
-    __shared__ __attribute__((aligned(16))) double WY[2 * kBatchObs * 18];   // W blocks, then Y blocks; later the exchange buffer
-    __shared__ double cil[kBatchPts * 6];     // inverse of the damped point blocks of the batch
-    __shared__ double gl[kBatchPts * 3];      // J_p^T r of the batch's points
-    __shared__ uint8_t tab[kBatchPts * KMAX];
-    __shared__ uint8_t pt_l[kBatchObs];       // batch-local point of each staged observation
-    double* const Wl = WY;
-    double* const Yl = WY + kBatchObs * 18;
     static_assert(NT >= 3 * kBatchObs, "W/Y staging uses three lanes per observation");
+    static_assert(KB % 4 == 0 && (2 * KB * LD) % 2 == 0, "image shape");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* const raw = lds;                              // [kBatchObs][36]
+    double* const Yi = raw + kBatchObs * kRawRow;         // [KB][LD]   Yi[3 pl + c][6 slot + r] = Y[r][c]
+    double* const Wi = Yi + KB * LD;                      // [KB][LD]
+    double* const cil = Wi + KB * LD;                     // [2][PB][6] inverse of the damped point blocks, by batch parity
+    double* const gl = cil + 2 * PB * 6;                  // [2][KB]    J_p^T r of the batch's points, index 3 pl + c
+    uint8_t* const pt_l = reinterpret_cast<uint8_t*>(gl + 2 * KB);   // batch-local point of each staged observation
+    uint8_t* const slot_l = pt_l + kBatchObs;                    // its window slot (255: fixed camera)
 
     const SchurChunk ch = chunks[blockIdx.x];
-    const int tid = threadIdx.x;
-    const int K = (int)ch.n_local;
-    const int n_pair = K * (K + 1) / 2, n_items = 2 * n_pair + K;
-    const int IPT = (n_items + NT - 1) / NT;                                  // > 1 only for wide windows
-    const int G = (IPT == 1 && n_items <= 2 * kBatchObs) ? max(1, min(NT / max(n_items, 1), 4)) : 1;
-    const int grp = IPT == 1 ? tid / max(n_items, 1) : 0;
+    const int tid = threadIdx.x, lane = tid % 64;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / 64);
+    const int K = (int)ch.n_local, rows_used = 6 * K;
+    const int ptl = tid - (NT - 64);   // point lane of the last wave (negative elsewhere)
 
-    int ia[MAX_IPT], ib[MAX_IPT], kind[MAX_IPT], slot_off[MAX_IPT];
-    double acc[MAX_IPT][18];
+    // this wave's tiles of the upper triangle: u = wave, wave + 8, ..
+    int t_i0[TPW], t_j0[TPW];
+    schur_double4 acc[TPW];
 #pragma unroll
-    for (int j = 0; j < MAX_IPT; j++) {
-        const int it = IPT == 1 ? tid % max(n_items, 1) : tid + j * NT;
-        ia[j] = 0; ib[j] = 0; kind[j] = 3; slot_off[j] = 0;
-        const bool live = (IPT == 1) ? (j == 0 && grp < G) : (it < n_items);
-        if (live && it < 2 * n_pair) {
-            int pair = it >> 1, a = 0;
-            const int pidx = pair;
-            while (pair >= K - a) { pair -= K - a; a++; }
-            ia[j] = a; ib[j] = a + pair;
-            kind[j] = it & 1;
-            slot_off[j] = pidx * 36 + (it & 1) * 18;            // position in the chunk's slab: pairs, then rhs
-        } else if (live && it < n_items) {
-            ia[j] = it - 2 * n_pair;
-            kind[j] = 2;
-            slot_off[j] = n_pair * 36 + ia[j] * 6;
+    for (int j = 0; j < TPW; j++) {
+        int u = wave + j * (NT / 64), ti = 0;
+        t_i0[j] = -1; t_j0[j] = 0;
+        if (u < NUP) {
+            while (u >= NT1 - ti) { u -= NT1 - ti; ti++; }
+            if (ti * 16 < rows_used && (ti + u) * 16 < rows_used) { t_i0[j] = ti * 16; t_j0[j] = (ti + u) * 16; }
         }
-#pragma unroll
-        for (int i = 0; i < 18; i++) acc[j][i] = 0.0;
+        acc[j] = schur_double4{0.0, 0.0, 0.0, 0.0};
     }
+    constexpr int kRhsGroups = KMAX <= 16 ? 4 : 2;   // kRhsGroups * 6 KMAX <= NT lanes share the rhs product
+    double racc = 0.0;   // partial rhs of row tid % rows_used
 
-    // Prefetch registers, one batch ahead: this lane's 16-byte pieces of the batch's (contiguous, point-major)
-    // Jacobian rows; its observation's point id and window slot; and - one lane per point - the point's
-    // J_p^T J_p, Jacobi scale and J_p^T r.
-    double2 pre[PPT];
+    // Prefetch registers, one batch ahead: this lane's 16-byte pieces of the batch's Jacobian rows (three passes of
+    // 512 lanes cover the 12 pieces of 128 J_c rows, two passes the 6 pieces of the [J_p | r] rows that hold J_p);
+    // its observation's point id and window slot; and - one lane per point - the point's J_p^T J_p, Jacobi scale
+    // and J_p^T r.  Everything that does not depend on the batch is worked out once, here; row offsets are 32-bit
+    // (the host refuses problems whose J_c array exceeds 4 GiB).
+    constexpr int kJcPieces = 12, kJpPieces = 6;
+    static_assert(PPT == 5 && 3 * NT == kBatchObs * kJcPieces && 2 * NT >= kBatchObs * kJpPieces, "piece passes");
+    double pre_x[PPT], pre_y[PPT];
     uint32_t pre_row[PPT];     // camera-major row of each piece's observation, fetched TWO batches ahead
     uint32_t pre_pt = 0;
     uint8_t pre_slot = 255;
     double pre_c[6], pre_s[3], pre_g[3];
-    auto fetch_index = [&](uint32_t bi) {
+    uint32_t p_pack[PPT];      // pass s: batch-local observation of this lane's piece | piece inside the row << 8
+#pragma unroll
+    for (int s = 0; s < PPT; s++) {
+        const int piece = tid + (s < 3 ? s : s - 3) * NT, per = s < 3 ? kJcPieces : kJpPieces;
+        const int o = piece / per, part = piece - o * per;        // o >= 128 in the idle tail of the last pass
+        p_pack[s] = (uint32_t)o | ((uint32_t)part << 8);
+    }
+    auto p_obs = [&](int s) __attribute__((always_inline)) { return (int)(p_pack[s] & 0xFFu); };
+    auto p_part = [&](int s) __attribute__((always_inline)) { return p_pack[s] >> 8; };
+    const char* const jc_b = reinterpret_cast<const char*>(jc);
+    const char* const jp_b = reinterpret_cast<const char*>(jpr);
+    auto fetch_index = [&](uint32_t bi) __attribute__((always_inline)) {
         const SchurBatch bt = batches[bi];
         const int nq = (int)(bt.q_end - bt.q_begin);
 #pragma unroll
-        for (int s = 0; s < PPT; s++) {
-            const int o = (tid + s * NT) / kRawPieces;
-            pre_row[s] = o < nq ? pt_obs[bt.q_begin + o] : 0u;
-        }
+        for (int s = 0; s < PPT; s++) pre_row[s] = p_obs(s) < nq ? pt_obs[bt.q_begin + p_obs(s)] : 0u;
     };
-    auto fetch = [&](uint32_t bi) {   // rows of batch bi through the indices fetch_index(bi) loaded earlier
+    auto fetch = [&](uint32_t bi) __attribute__((always_inline)) {   // rows of batch bi through the indices fetch_index(bi) loaded earlier
         const SchurBatch bt = batches[bi];
         const int nq = (int)(bt.q_end - bt.q_begin), np = (int)(bt.p_end - bt.p_begin);
 #pragma unroll
         for (int s = 0; s < PPT; s++) {
-            const int piece = tid + s * NT, o = piece / kRawPieces, part = piece % kRawPieces;
-            pre[s] = make_double2(0.0, 0.0);
-            if (o < nq) {
-                const size_t q = pre_row[s];
-                pre[s] = part < 12 ? reinterpret_cast<const double2*>(jc + kJcRow * q)[part]
-                                   : reinterpret_cast<const double2*>(jpr + kJprRow * q)[part - 12];
-            }
+            // unconditional: idle lanes carry row 0 from fetch_index and read a valid (cached) piece they never store
+            const uint32_t off = pre_row[s] * (uint32_t)((s < 3 ? kJcRow : kJprRow) * 8) + p_part(s) * 16u;
+            const double2 v = *reinterpret_cast<const double2*>((s < 3 ? jc_b : jp_b) + off);
+            pre_x[s] = v.x; pre_y[s] = v.y;
         }
         if (tid < nq) { pre_pt = q_pt[bt.q_begin + tid]; pre_slot = q_slot[bt.q_begin + tid]; }
-        if (tid < np) {
-            const size_t p = (size_t)bt.p_begin + tid;
+        if (ptl >= 0 && ptl < np) {
+            const size_t p = (size_t)bt.p_begin + ptl;
 #pragma unroll
             for (int i = 0; i < 6; i++) pre_c[i] = C[6 * p + i];
 #pragma unroll
             for (int i = 0; i < 3; i++) { pre_s[i] = sp[3 * p + i]; pre_g[i] = gp[3 * p + i]; }
         }
     };
+    // One lane per point of a batch (the last wave, which owns the fewest tiles): damped 3x3 block inverted in
+    // registers, for the batch AFTER the one being multiplied - a long dependent f64 chain on 16 lanes that would
+    // otherwise stall all eight waves at a barrier.  Results go to the parity buffer of that batch.
+    auto point_phase = [&](uint32_t bi) __attribute__((always_inline)) {
+        if (ptl < 0 || ptl >= PB) return;
+        const SchurBatch bt = batches[bi];
+        const int np = (int)(bt.p_end - bt.p_begin);
+        double* cl = cil + (bi & 1) * (PB * 6);
+        double* g = gl + (bi & 1) * KB;
+        if (ptl < np) {
+            double ci[6];
+            const double m[6] = {pre_c[0] + point_lambda(pre_c[0], pre_s[0], lm), pre_c[1], pre_c[2],
+                                 pre_c[3] + point_lambda(pre_c[3], pre_s[1], lm), pre_c[4], pre_c[5] + point_lambda(pre_c[5], pre_s[2], lm)};
+            if (!sym3_inverse(m, ci)) scal[SC_SCHUR_STATUS] = 1.0;
+            double* o = Cinv + 6 * ((size_t)bt.p_begin + ptl);
+#pragma unroll
+            for (int i = 0; i < 6; i++) { cl[ptl * 6 + i] = ci[i]; o[i] = ci[i]; }
+            g[ptl * 3] = pre_g[0]; g[ptl * 3 + 1] = pre_g[1]; g[ptl * 3 + 2] = pre_g[2];
+        } else {
+            g[ptl * 3] = 0.0; g[ptl * 3 + 1] = 0.0; g[ptl * 3 + 2] = 0.0;   // k padding of the rhs product
+        }
+    };
     if (ch.batch_begin < ch.batch_end) {
         fetch_index(ch.batch_begin);
         fetch(ch.batch_begin);
         if (ch.batch_begin + 1 < ch.batch_end) fetch_index(ch.batch_begin + 1);
+        point_phase(ch.batch_begin);
     }
 
     for (uint32_t bi = ch.batch_begin; bi < ch.batch_end; bi++) {
         const SchurBatch bt = batches[bi];
         const int nq = (int)(bt.q_end - bt.q_begin), np = (int)(bt.p_end - bt.p_begin);
-        __syncthreads();   // previous batch's accumulation is done with the LDS images
+        const int kb_used = (3 * np + 3) & ~3;
+        lds_barrier();   // previous batch's products are done with the LDS images
 #pragma unroll
-        for (int s = 0; s < PPT; s++) {
-            const int piece = tid + s * NT;
-            if (piece < kBatchObs * kRawPieces) reinterpret_cast<double2*>(raw)[piece] = pre[s];
-        }
-        for (int i = tid; i < np * KMAX; i += NT) tab[i] = 255;
-        if (tid < np) {
-            // one lane per point: damped 3x3 block inverted in registers
-            double m[6] = {pre_c[0], pre_c[1], pre_c[2], pre_c[3], pre_c[4], pre_c[5]}, ci[6];
-            m[0] += point_lambda(pre_c[0], pre_s[0], lm);
-            m[3] += point_lambda(pre_c[3], pre_s[1], lm);
-            m[5] += point_lambda(pre_c[5], pre_s[2], lm);
-            if (!sym3_inverse(m, ci)) scal[SC_SCHUR_STATUS] = 1.0;
-            double* o = Cinv + 6 * ((size_t)bt.p_begin + tid);
-#pragma unroll
-            for (int i = 0; i < 6; i++) { cil[tid * 6 + i] = ci[i]; o[i] = ci[i]; }
-            gl[tid * 3] = pre_g[0]; gl[tid * 3 + 1] = pre_g[1]; gl[tid * 3 + 2] = pre_g[2];
-        }
+        for (int s = 0; s < PPT; s++)
+            if (p_obs(s) < nq) reinterpret_cast<double2*>(raw)[p_obs(s) * kRawPieces + (s < 3 ? 0 : kJcPieces) + (int)p_part(s)] = make_double2(pre_x[s], pre_y[s]);
         const uint32_t my_pt = pre_pt;
         const uint8_t my_slot = pre_slot;
-        if (tid < nq) pt_l[tid] = (uint8_t)(my_pt - bt.p_begin);
-        __syncthreads();
-        if (tid < nq && my_slot != 255) tab[(int)(my_pt - bt.p_begin) * KMAX + my_slot] = (uint8_t)tid;
-        // W = J_c^T J_p and Y = W Cinv: three lanes per observation, two of the six rows each
-        if (tid < 3 * nq) {
-            const int o = tid / 3, r0 = (tid % 3) * 2;
-            const double* row = raw + o * kRawRow;
-            const double* b = row + 24;
-            const double* ci = cil + (int)pt_l[o] * 6;
-            const double c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3], c4 = ci[4], c5 = ci[5];
-            const double b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5], b6 = b[6], b7 = b[7], b8 = b[8],
-                         b9 = b[9], b10 = b[10], b11 = b[11];
-#pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const int r = r0 + rr;
-                const double a0 = row[r], a1 = row[6 + r], a2 = row[12 + r], a3 = row[18 + r];
-                const double w0 = a0 * b0 + a1 * b3 + a2 * b6 + a3 * b9;
-                const double w1 = a0 * b1 + a1 * b4 + a2 * b7 + a3 * b10;
-                const double w2 = a0 * b2 + a1 * b5 + a2 * b8 + a3 * b11;
-                double* Wt = Wl + o * 18 + r * 3;
-                double* Yt = Yl + o * 18 + r * 3;
-                Wt[0] = w0; Wt[1] = w1; Wt[2] = w2;
-                Yt[0] = w0 * c0 + w1 * c1 + w2 * c2;
-                Yt[1] = w0 * c1 + w1 * c3 + w2 * c4;
-                Yt[2] = w0 * c2 + w1 * c4 + w2 * c5;
-            }
-        }
-        __syncthreads();
-        if (bi + 1 < ch.batch_end) {                 // in flight while this batch is accumulated
+        // the prefetch registers are free again: request the next batch now, a whole batch time ahead of its use
+        if (bi + 1 < ch.batch_end) {
             fetch(bi + 1);
             if (bi + 2 < ch.batch_end) fetch_index(bi + 2);
         }
-        for (int pl = grp; pl < np; pl += G) {
-            const uint8_t* trow = tab + pl * KMAX;
+        // zero both images (contiguous, 16-byte stores); absent cameras and the k padding stay zero
+        for (int e = tid; e < KB * LD; e += NT) reinterpret_cast<double2*>(Yi)[e] = make_double2(0.0, 0.0);
+        if (tid < nq) { pt_l[tid] = (uint8_t)(my_pt - bt.p_begin); slot_l[tid] = my_slot; }
+        const double* const cil_b = cil + (bi & 1) * (PB * 6);
+        const double* const gl_b = gl + (bi & 1) * KB;
+        lds_barrier();
+        // W = J_c^T J_p and Y = W Cinv: three lanes per observation, two of the six rows each
+        if (tid < 3 * nq) {
+            const int o = tid / 3, r0 = (tid % 3) * 2;
+            const int slot = slot_l[o];
+            if (slot != 255) {
+                const double* row = raw + o * kRawRow;
+                const double* b = row + 24;
+                const int pl = pt_l[o];
+                const double* ci = cil_b + pl * 6;
+                const double c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3], c4 = ci[4], c5 = ci[5];
+                const double b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5], b6 = b[6], b7 = b[7], b8 = b[8],
+                             b9 = b[9], b10 = b[10], b11 = b[11];
+                double* Wc = Wi + (pl * 3) * LD + slot * 6;
+                double* Yc = Yi + (pl * 3) * LD + slot * 6;
 #pragma unroll
-            for (int j = 0; j < MAX_IPT; j++) {
-                if (kind[j] < 2) {
-                    const int ta = trow[ia[j]], tb = trow[ib[j]];
-                    if (ta != 255 && tb != 255) {
-                        const double* Y = Yl + ta * 18 + kind[j] * 9;
-                        const double* W = Wl + tb * 18;
-#pragma unroll
-                        for (int r = 0; r < 3; r++)
-#pragma unroll
-                            for (int c = 0; c < 6; c++)
-                                acc[j][r * 6 + c] += Y[r * 3] * W[c * 3] + Y[r * 3 + 1] * W[c * 3 + 1] + Y[r * 3 + 2] * W[c * 3 + 2];
-                    }
-                } else if (kind[j] == 2) {
-                    const int ta = trow[ia[j]];
-                    if (ta != 255) {
-                        const double* Y = Yl + ta * 18;
-                        const double* g = gl + pl * 3;
-#pragma unroll
-                        for (int r = 0; r < 6; r++) acc[j][r] += Y[r * 3] * g[0] + Y[r * 3 + 1] * g[1] + Y[r * 3 + 2] * g[2];
-                    }
+                for (int rr = 0; rr < 2; rr++) {
+                    const int r = r0 + rr;
+                    const double a0 = row[r], a1 = row[6 + r], a2 = row[12 + r], a3 = row[18 + r];
+                    const double w0 = a0 * b0 + a1 * b3 + a2 * b6 + a3 * b9;
+                    const double w1 = a0 * b1 + a1 * b4 + a2 * b7 + a3 * b10;
+                    const double w2 = a0 * b2 + a1 * b5 + a2 * b8 + a3 * b11;
+                    Wc[r] = w0; Wc[LD + r] = w1; Wc[2 * LD + r] = w2;
+                    Yc[r] = w0 * c0 + w1 * c1 + w2 * c2;
+                    Yc[LD + r] = w0 * c1 + w1 * c3 + w2 * c4;
+                    Yc[2 * LD + r] = w0 * c2 + w1 * c4 + w2 * c5;
                 }
             }
         }
+        lds_barrier();
+        // window += Yi^T Wi over the batch's columns: lane l feeds A[i = l%16][k = l/16] and B[k = l/16][j = l%16].
+        // k outermost: the wave's tiles are independent accumulators, their products issue back to back
+        {
+            const double* pa[TPW];
+            const double* pb[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; j++) {
+                const int i0 = t_i0[j] < 0 ? 0 : t_i0[j];
+                pa[j] = Yi + (lane / 16) * LD + i0 + lane % 16;
+                pb[j] = Wi + (lane / 16) * LD + t_j0[j] + lane % 16;
+            }
+            for (int k0 = 0; k0 < kb_used; k0 += 4) {
+                double av[TPW], bv[TPW];
+#pragma unroll
+                for (int j = 0; j < TPW; j++) { av[j] = pa[j][k0 * LD]; bv[j] = pb[j][k0 * LD]; }
+#pragma unroll
+                for (int j = 0; j < TPW; j++)
+                    if (t_i0[j] >= 0) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j], acc[j], 0, 0, 0);   // wave-uniform
+            }
+        }
+        // rhs part Y g: lane group g = tid / rows_used takes the columns k = g (mod kRhsGroups); combined at the end
+        if (tid < kRhsGroups * rows_used) {
+            const int grp = tid / rows_used, rrow = tid - grp * rows_used;
+            const double* y = Yi + rrow;
+            double s0 = 0.0, s1 = 0.0;
+            int k = grp;
+            for (; k + kRhsGroups < kb_used; k += 2 * kRhsGroups) {
+                s0 += y[k * LD] * gl_b[k];
+                s1 += y[(k + kRhsGroups) * LD] * gl_b[k + kRhsGroups];
+            }
+            if (k < kb_used) s0 += y[k * LD] * gl_b[k];
+            racc += s0 + s1;
+        }
+        if (bi + 1 < ch.batch_end) point_phase(bi + 1);   // its inputs were requested at the top of this iteration
     }
 
-    // combine the lane groups (fixed order: group 1, 2, 3 onto group 0) through the staging LDS
-    if (G > 1) {
-        for (int g = 1; g < G; g++) {
-            __syncthreads();
-            if (grp == g && kind[0] != 3) {
-                double* o = WY + (tid % n_items) * 18;     // n_items <= 2 * kBatchObs here
+    // the chunk's window: [pair a <= b][6x6] then [camera][6].  Accumulator register r of lane l holds element
+    // (i0 + 4 r + l/16, j0 + l%16); the same-camera blocks are symmetric (W Cinv W^T), so their lower entries are the
+    // mirrored upper ones, wherever the 16x16 tiling cuts them.
+    double* out = slab + chunk_slab[blockIdx.x];
+    const int n_pair = K * (K + 1) / 2;
 #pragma unroll
-                for (int i = 0; i < 18; i++) o[i] = acc[0][i];
-            }
-            __syncthreads();
-            if (grp == 0 && kind[0] != 3) {
-                const double* o = WY + tid * 18;
+    for (int j = 0; j < TPW; j++) {
+        if (t_i0[j] < 0) continue;
 #pragma unroll
-                for (int i = 0; i < 18; i++) acc[0][i] += o[i];
+        for (int r = 0; r < 4; r++) {
+            const int row = t_i0[j] + 4 * r + lane / 16, col = t_j0[j] + lane % 16;
+            if (row >= rows_used || col >= rows_used) continue;
+            const int a = row / 6, rr = row - 6 * a, b = col / 6, cc = col - 6 * b;
+            if (a > b) continue;
+            const int pidx = a * K - a * (a - 1) / 2 + (b - a);
+            double* blk = out + pidx * 36;
+            const double v = acc[j][r];
+            if (a < b) {
+                blk[rr * 6 + cc] = v;
+            } else if (row <= col) {
+                blk[rr * 6 + cc] = v;
+                if (row < col) blk[cc * 6 + rr] = v;
             }
         }
     }
-    // the chunk's window: [pair][6x6] then [camera][6], contiguous => coalesced plain stores
-    double* out = slab + chunk_slab[blockIdx.x];
+    // rhs: the lane groups' partial sums are added in a fixed order through the (now idle) image memory
+    __syncthreads();
+    if (tid < kRhsGroups * rows_used) Yi[tid] = racc;
+    __syncthreads();
+    if (tid < rows_used) {
+        double s = Yi[tid];
 #pragma unroll
-    for (int j = 0; j < MAX_IPT; j++) {
-        if (grp != 0) break;
-        if (kind[j] < 2) {
-#pragma unroll
-            for (int i = 0; i < 18; i++) out[slot_off[j] + i] = acc[j][i];
-        } else if (kind[j] == 2) {
-#pragma unroll
-            for (int r = 0; r < 6; r++) out[slot_off[j] + r] = acc[j][r];
-        }
+        for (int g = 1; g < kRhsGroups; g++) s += Yi[g * rows_used + tid];
+        out[n_pair * 36 + tid] = s;
     }
 }
 
@@ -804,12 +861,17 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
                   double* scal)
 {
     if (!n_chunks) return;
-    if (kmax <= 16)
-        hipLaunchKernelGGL((ba_schur_kernel<16, 384>), dim3(n_chunks), dim3(384), 0, s, chunks, batches, chunk_slab, pt_obs, q_pt, q_slot,
-                           jc, jpr, C, gp, sp, lm, Cinv, slab, scal);
-    else
-        hipLaunchKernelGGL((ba_schur_kernel<32, 576>), dim3(n_chunks), dim3(576), 0, s, chunks, batches, chunk_slab, pt_obs, q_pt, q_slot,
-                           jc, jpr, C, gp, sp, lm, Cinv, slab, scal);
+    if (kmax <= 16) {
+        constexpr size_t lds = SchurShape<16>::lds_bytes;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ba_schur_kernel<16>), dim3(n_chunks), dim3(kSchurThreads), lds, s, chunks, batches, chunk_slab, pt_obs, q_pt,
+                           q_slot, jc, jpr, C, gp, sp, lm, Cinv, slab, scal);
+    } else {
+        constexpr size_t lds = SchurShape<32>::lds_bytes;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(kSchurThreads), lds, s, chunks, batches, chunk_slab, pt_obs, q_pt,
+                           q_slot, jc, jpr, C, gp, sp, lm, Cinv, slab, scal);
+    }
 }
 
 void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts, const uint32_t* lo_row, const uint32_t* lo_cam_off,

@@ -362,7 +362,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             uint32_t bp = chunk_p0;
             while (bp < p_end) {
                 uint32_t be = bp, nq = 0;
-                while (be < p_end && (be - bp) < (uint32_t)kBatchPts && nq + (pt_start[be + 1] - pt_start[be]) <= (uint32_t)kBatchObs) {
+                while (be < p_end && (be - bp) < (uint32_t)schur_batch_points(K) && nq + (pt_start[be + 1] - pt_start[be]) <= (uint32_t)kBatchObs) {
                     nq += pt_start[be + 1] - pt_start[be];
                     be++;
                 }
