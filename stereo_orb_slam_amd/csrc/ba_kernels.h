@@ -25,7 +25,8 @@ constexpr int kPointBlock = 256;     // threads per block of the per-point kerne
 enum {
     SC_COST_X = 0,                                    // this rank's cost at the linearisation point
     SC_CAND_COST = 1, SC_MCC_PTS = 2, SC_STEP2_PTS = 3, SC_X2_PTS = 4, SC_GDOT_PTS = 5,  // summed over ranks
-    SC_GMAX_PTS = 6, SC_SCHUR_STATUS = 7,
+    SC_GMAX_PTS = 6,                                  // max over ranks; slots 2..6 are written as one group by sum5
+    SC_SCHUR_STATUS = 7,                              // rank-local; spread through the candidate cost (launch_status_poison)
     SC_MCC_CAM = 8, SC_STEP2_CAM = 9, SC_X2_CAM = 10, SC_GDOT_CAM = 11, SC_GMAX_CAM = 12,  // replicated
     SC_LIN_ITERS = 13, SC_LIN_RESID = 14, SC_LIN_STATUS = 15,
     SC_COUNT = 16
@@ -89,6 +90,10 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
                   const uint32_t* chunk_slab, const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* jc,
                   const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* slab,
                   double* scal);
+
+// Multi-rank jobs: a rank whose point elimination failed (SC_SCHUR_STATUS) turns its share of the candidate cost
+// into +inf before the scalars are summed, so every rank sees a non-finite candidate and rejects the step alike.
+void launch_status_poison(hipStream_t s, double* scal);
 
 // long-track points (see LongPoint): damped point block inverse, W / Y of every free-camera observation into
 // wy[lo][36] and Y g into the slab at lo_cam_off[lo]; then Y_a W_b^T of every listed pair into the slab at pair_off

@@ -874,6 +874,13 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
     }
 }
 
+__global__ void ba_status_poison_kernel(double* __restrict__ scal)
+{
+    if (scal[SC_SCHUR_STATUS] != 0.0) scal[SC_CAND_COST] = __builtin_huge_val();
+}
+
+void launch_status_poison(hipStream_t s, double* scal) { hipLaunchKernelGGL(ba_status_poison_kernel, dim3(1), dim3(1), 0, s, scal); }
+
 void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts, const uint32_t* lo_row, const uint32_t* lo_cam_off,
                        uint32_t n_pairs, const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* pair_off, const double* jc,
                        const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* wy,

@@ -709,6 +709,7 @@ int take_step(soslam_ba* h, double radius)
     }
     {
         StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
+        if (h->world > 1) launch_status_poison(s, h->scalp());
         SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_CAND_COST, 5, SOSLAM_REDUCE_SUM));
         if (h->opt.check_termination) SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_GMAX_PTS, 1, SOSLAM_REDUCE_MAX));
     }
@@ -799,7 +800,8 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         e.cost = sc.x_cost; e.radius = radius; e.gradient_max_norm = sc.gmax;
         e.model_cost_change = sc.mcc; e.linear_iterations = sc.lin_iters;
         sum.linear_iterations += sc.lin_iters;
-        const bool lin_ok = sc.schur_status == 0 && sc.lin_status == 0 && std::isfinite(sc.mcc);
+        // a non-finite candidate cost is how another rank's failed point elimination arrives here (launch_status_poison)
+        const bool lin_ok = sc.schur_status == 0 && sc.lin_status == 0 && std::isfinite(sc.mcc) && std::isfinite(sc.cand_cost);
         if (!lin_ok || !(sc.mcc > 0.0)) {
             e.valid = 0;
             h->log.push_back(e);

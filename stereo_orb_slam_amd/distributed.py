@@ -27,6 +27,7 @@ class TorchAllReduce:
         self.base = tensor.data_ptr()
         self.count = tensor.numel()
         self.group = group
+        self.host_staged = False   # set by attach() for backends that stage device tensors through the host (gloo)
         self.calls = 0
         self.elements = 0
 
@@ -35,10 +36,26 @@ class TorchAllReduce:
         off = (ptr - self.base) // 8
         if (ptr - self.base) % 8 or off < 0 or off + count > self.count:
             return 1
-        # The library launches on torch's current stream (soslam_ba_options.stream), and the process group
-        # orders its collective after that stream's pending work and before its later work.
-        dist.all_reduce(self.tensor[off:off + count],
-                        op=dist.ReduceOp.SUM if op == _lib.REDUCE_SUM else dist.ReduceOp.MAX, group=self.group)
+        # The process group orders its collective after the pending work of torch's CURRENT stream and that stream's
+        # later work after the collective.  The library's kernels run on the stream it passes here - its own
+        # non-blocking stream unless soslam_ba_options.stream named another - so that stream is made current for
+        # the call; relying on the caller's current stream would be a race whenever the two differ.
+        view = self.tensor[off:off + count]
+        rop = dist.ReduceOp.SUM if op == _lib.REDUCE_SUM else dist.ReduceOp.MAX
+        if self.tensor.is_cuda:
+            dev = self.tensor.device
+            lib_stream = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+            with torch.cuda.stream(lib_stream):
+                if self.host_staged:
+                    # gloo stages device tensors through host memory on streams of its own; seen on this image: its
+                    # copy back can still be in flight when the call returns.  Rehearsal backend only - be blunt.
+                    lib_stream.synchronize()
+                    dist.all_reduce(view, op=rop, group=self.group)
+                    torch.cuda.synchronize(dev)
+                else:
+                    dist.all_reduce(view, op=rop, group=self.group)
+        else:
+            dist.all_reduce(view, op=rop, group=self.group)
         self.calls += 1
         self.elements += count
         return 0
@@ -50,6 +67,8 @@ def attach(handle, rank: int, world: int, device, group=None) -> TorchAllReduce:
     t = torch.zeros(n, dtype=torch.float64, device=device)
     handle.set_reduce_buffer(t.data_ptr(), n)
     cb = TorchAllReduce(t, group)
+    import torch.distributed as dist
+    cb.host_staged = t.is_cuda and dist.get_backend(group) != "nccl"
     handle.set_allreduce(cb, rank, world)
     handle._reduce_tensor = t   # keep alive as long as the handle
     return cb
