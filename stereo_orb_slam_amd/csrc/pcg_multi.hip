@@ -149,9 +149,19 @@ __global__ void pcgm_bb_kernel(const PcgBufs w)
     if (threadIdx.x == 0 && blockIdx.x == 0) w.state[ST_BB] = sum_partials(w.part_rr, w.n_wg);
 }
 
-__device__ __forceinline__ bool converged(const PcgBufs& w, int parity, double tol)
+// Sum of the per-workgroup partials by the whole workgroup: lane t adds every 256th value, then the fixed tree of
+// block_sum256.  Every workgroup runs the same code on the same data, so all of them get the same bits - and none
+// walks the list alone (120 dependent-latency loads per lane at 5000 block rows was most of an iteration).
+__device__ __forceinline__ double coop_sum(const double* __restrict__ part, uint32_t n, double* red)
 {
-    const double rr = sum_partials(w.part_rr + parity * w.n_wg, w.n_wg);
+    double v = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += kThreads) v += part[i];
+    return block_sum256(v, red);
+}
+
+__device__ __forceinline__ bool converged(const PcgBufs& w, int parity, double tol, double* red)
+{
+    const double rr = coop_sum(w.part_rr + parity * w.n_wg, w.n_wg, red);
     const double bb = w.state[ST_BB];
     return !(rr > tol * tol * bb) || w.state[ST_BREAKDOWN] != 0.0;
 }
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void pcgm_matvec_kernel(const BsrView A, 
                                                                const int parity, const double tol)
 {
     __shared__ double red[4];
-    if (converged(w, parity, tol)) return;
+    if (converged(w, parity, tol, red)) return;
     const uint32_t n = A.n_rows * 6;
     const int t = threadIdx.x;
     const uint32_t i = blockIdx.x * kRowsPerWg * 6 + t;
@@ -180,9 +190,9 @@ __global__ __launch_bounds__(kThreads) void pcgm_update_kernel(const uint32_t n,
 {
     __shared__ double red[4];
     __shared__ double rloc[kRowsPerWg * 6];
-    if (converged(w, parity, tol)) return;
-    const double pq = sum_partials(w.part_pq, w.n_wg);
-    const double rz = sum_partials(w.part_rz + parity * w.n_wg, w.n_wg);
+    if (converged(w, parity, tol, red)) return;
+    const double pq = coop_sum(w.part_pq, w.n_wg, red);
+    const double rz = coop_sum(w.part_rz + parity * w.n_wg, w.n_wg, red);
     const int t = threadIdx.x;
     if (!(pq > 0.0)) {
         if (t == 0 && blockIdx.x == 0) w.state[ST_BREAKDOWN] = 2.0;
@@ -220,9 +230,10 @@ __global__ __launch_bounds__(kThreads) void pcgm_update_kernel(const uint32_t n,
 __global__ __launch_bounds__(kThreads) void pcgm_direction_kernel(const uint32_t n, const PcgBufs w, const int parity, const double tol)
 {
     // the update kernel ran iff the system had not converged at `parity`; it may have converged now - p is then unused
-    if (converged(w, parity, tol)) return;
-    const double rz_old = sum_partials(w.part_rz + parity * w.n_wg, w.n_wg);
-    const double rz_new = sum_partials(w.part_rz + (parity ^ 1) * w.n_wg, w.n_wg);
+    __shared__ double red[4];
+    if (converged(w, parity, tol, red)) return;
+    const double rz_old = coop_sum(w.part_rz + parity * w.n_wg, w.n_wg, red);
+    const double rz_new = coop_sum(w.part_rz + (parity ^ 1) * w.n_wg, w.n_wg, red);
     const double beta = rz_new / rz_old;
     const int t = threadIdx.x;
     const uint32_t i = blockIdx.x * kRowsPerWg * 6 + t;
