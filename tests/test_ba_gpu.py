@@ -500,3 +500,37 @@ def test_full_size_properties_config3(gpu):
     for solver in (2, 3):   # PCG (band-preconditioned) and direct band Cholesky against the dense factorisation
         assert res[1][0] == pytest.approx(res[solver][0], rel=REL_COST)
         assert np.abs(res[1][1] - res[solver][1]).max() < ABS_POSE
+
+
+def test_empty_and_ragged_problems(gpu, oracle_lib, prob1):
+    """What the gather of BundleAdjuster::Optimize can hand over at the edges: a window without observations, a point
+    nobody observes, a free camera that observes nothing, a single observation.  All must solve (cost never rises, no
+    error), unobserved parameters must come back unchanged, and the rest must match the oracle."""
+    ba, synth, L = gpu
+    o = ba.default_options(max_iterations=5)
+    # (1) no observations at all: nothing to do, cost 0
+    empty = synth.BaProblem(prob1.poses_wc[:2], prob1.points[:3], np.zeros(0, np.uint32), np.zeros(0, np.uint32),
+                            np.zeros((0, 4), np.float32), prob1.proj_l, prob1.proj_r)
+    cams, pts, summ = ba.optimize(empty, o)
+    assert summ.initial_cost == 0.0 and summ.final_cost == 0.0
+    np.testing.assert_array_equal(cams, empty.poses_cw())
+    np.testing.assert_array_equal(pts, empty.points_f64())
+    # (2) one extra point and one extra (free) camera that take part in no observation
+    extra_pose = prob1.poses_wc[-1:].copy()
+    extra_pose[0, 0, 3] += 1.0
+    rag = synth.BaProblem(np.concatenate([prob1.poses_wc, extra_pose]), np.concatenate([prob1.points, [[1.0, 2.0, 30.0]]]).astype(np.float32),
+                          prob1.obs_cam, prob1.obs_pt, prob1.obs_uv, prob1.proj_l, prob1.proj_r)
+    cams, pts, summ = ba.optimize(rag, o)
+    ocams, opts_, osum, _ = _oracle_solve(oracle_lib, prob1, max_iterations=5)
+    assert summ.final_cost == pytest.approx(osum.final_cost, rel=REL_COST)
+    assert np.abs(cams[:-1] - ocams).max() < ABS_POSE
+    np.testing.assert_array_equal(cams[-1], rag.poses_cw()[-1])       # untouched
+    np.testing.assert_array_equal(pts[-1], rag.points_f64()[-1])      # untouched
+    # (3) a single observation: one fixed camera, one point (4 residuals, 3 unknowns)
+    k = 0
+    one = synth.BaProblem(prob1.poses_wc[prob1.obs_cam[k]:prob1.obs_cam[k] + 1], prob1.points[prob1.obs_pt[k]:prob1.obs_pt[k] + 1],
+                          np.zeros(1, np.uint32), np.zeros(1, np.uint32), prob1.obs_uv[k:k + 1], prob1.proj_l, prob1.proj_r)
+    cams, pts, summ = ba.optimize(one, ba.default_options(max_iterations=20))
+    ocams, opts_, osum, _ = _oracle_solve(oracle_lib, one, max_iterations=20)
+    assert summ.final_cost <= summ.initial_cost
+    _compare_solutions(summ, cams, pts, osum, ocams, opts_)
