@@ -20,6 +20,8 @@ constexpr int kBatchObs = 128;       // observations staged per Schur batch
 // [3 PB][6 KMAX + 1] f64 images must fit LDS next to the staged rows
 constexpr int schur_batch_points(int kmax) { return kmax <= 16 ? 16 : 8; }
 constexpr int kPointBlock = 256;     // threads per block of the per-point kernels
+constexpr int kBacksubLanes = 4;     // lanes that share one point in ba_backsub
+constexpr uint32_t backsub_blocks(uint32_t n_pt) { return (uint32_t)(((uint64_t)n_pt * kBacksubLanes + kPointBlock - 1) / kPointBlock); }
 
 // scalar slots (device f64)
 enum {

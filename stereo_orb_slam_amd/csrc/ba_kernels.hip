@@ -254,21 +254,32 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n
                                                                       const double* __restrict__ jpr,
                                                                       double* __restrict__ C, double* __restrict__ gp)
 {
-    const uint32_t p = blockIdx.x * kPointBlock + threadIdx.x;
-    if (p >= n_pt) return;
+    // kBacksubLanes lanes per point share its observations (a gather: more rows in flight), fixed butterfly at the end
+    const uint32_t p = (blockIdx.x * kPointBlock + threadIdx.x) / kBacksubLanes;
+    const uint32_t sub = threadIdx.x % kBacksubLanes;
+    const bool live = p < n_pt;
     double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2 = 0;
-    for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
-        const double2* row = reinterpret_cast<const double2*>(jpr + kJprRow * (size_t)pt_obs[q]);
-        double w[16];
+    if (live) {
+        for (uint32_t q = pt_start[p] + sub; q < pt_start[p + 1]; q += kBacksubLanes) {
+            const double2* row = reinterpret_cast<const double2*>(jpr + kJprRow * (size_t)pt_obs[q]);
+            double w[16];
 #pragma unroll
-        for (int i = 0; i < 8; i++) { const double2 d = row[i]; w[2 * i] = d.x; w[2 * i + 1] = d.y; }
+            for (int i = 0; i < 8; i++) { const double2 d = row[i]; w[2 * i] = d.x; w[2 * i + 1] = d.y; }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const double a = w[i * 3], b = w[i * 3 + 1], c = w[i * 3 + 2], r = w[12 + i];
-            c0 += a * a; c1 += a * b; c2 += a * c; c3 += b * b; c4 += b * c; c5 += c * c;
-            g0 += a * r; g1 += b * r; g2 += c * r;
+            for (int i = 0; i < 4; i++) {
+                const double a = w[i * 3], b = w[i * 3 + 1], c = w[i * 3 + 2], r = w[12 + i];
+                c0 += a * a; c1 += a * b; c2 += a * c; c3 += b * b; c4 += b * c; c5 += c * c;
+                g0 += a * r; g1 += b * r; g2 += c * r;
+            }
         }
     }
+#pragma unroll
+    for (int off = 1; off < kBacksubLanes; off <<= 1) {
+        c0 += __shfl_xor(c0, off, kWave); c1 += __shfl_xor(c1, off, kWave); c2 += __shfl_xor(c2, off, kWave);
+        c3 += __shfl_xor(c3, off, kWave); c4 += __shfl_xor(c4, off, kWave); c5 += __shfl_xor(c5, off, kWave);
+        g0 += __shfl_xor(g0, off, kWave); g1 += __shfl_xor(g1, off, kWave); g2 += __shfl_xor(g2, off, kWave);
+    }
+    if (!live || sub != 0) return;
     double* Cp = C + 6 * (size_t)p;
     Cp[0] = c0; Cp[1] = c1; Cp[2] = c2; Cp[3] = c3; Cp[4] = c4; Cp[5] = c5;
     double* g = gp + 3 * (size_t)p;
@@ -745,25 +756,44 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
     double* __restrict__ part)
 {
     __shared__ double red[(kPointBlock / kWave) * 5];
-    const uint32_t p = blockIdx.x * kPointBlock + threadIdx.x;
+    // kBacksubLanes lanes per point share its observations (more rows in flight per CU: the kernel is a gather),
+    // their partial sums meet in a fixed butterfly; lane 0 of the group finishes the point
+    const uint32_t p = (blockIdx.x * kPointBlock + threadIdx.x) / kBacksubLanes;
+    const uint32_t sub = threadIdx.x % kBacksubLanes;
     double mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
-    if (p < n_pt) {
-        const double g[3] = {gp[3 * (size_t)p], gp[3 * (size_t)p + 1], gp[3 * (size_t)p + 2]};
-        double t0 = g[0], t1 = g[1], t2 = g[2];
-        for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
+    const bool live = p < n_pt;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    if (live) {
+        // all 18 16-byte pieces of an observation's two rows are requested before the first multiply, and two
+        // observations are in flight per lane: this kernel is a gather of 320 B per observation
+#pragma unroll 2
+        for (uint32_t q = pt_start[p] + sub; q < pt_start[p + 1]; q += kBacksubLanes) {
             const size_t k = pt_obs[q];
             const double* d = dc_full + 6 * (size_t)q_cam[q];
-            const double d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
             const double2* jcr = reinterpret_cast<const double2*>(jc + kJcRow * k);
             const double2* jr = reinterpret_cast<const double2*>(jpr + kJprRow * k);
+            double2 a[12], b[6];
+#pragma unroll
+            for (int i = 0; i < 12; i++) a[i] = jcr[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) b[i] = jr[i];
+            const double d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
+            const double jp[12] = {b[0].x, b[0].y, b[1].x, b[1].y, b[2].x, b[2].y, b[3].x, b[3].y, b[4].x, b[4].y, b[5].x, b[5].y};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const double2 a0 = jcr[i * 3], a1 = jcr[i * 3 + 1], a2 = jcr[i * 3 + 2];
-                const double m = a0.x * d0 + a0.y * d1 + a1.x * d2 + a1.y * d3 + a2.x * d4 + a2.y * d5;
-                const double* jp = reinterpret_cast<const double*>(jr) + i * 3;
-                t0 += jp[0] * m; t1 += jp[1] * m; t2 += jp[2] * m;
+                const double m = a[i * 3].x * d0 + a[i * 3].y * d1 + a[i * 3 + 1].x * d2 + a[i * 3 + 1].y * d3 + a[i * 3 + 2].x * d4 +
+                                 a[i * 3 + 2].y * d5;
+                t0 += jp[i * 3] * m; t1 += jp[i * 3 + 1] * m; t2 += jp[i * 3 + 2] * m;
             }
         }
+    }
+#pragma unroll
+    for (int off = 1; off < kBacksubLanes; off <<= 1) {
+        t0 += __shfl_xor(t0, off, kWave); t1 += __shfl_xor(t1, off, kWave); t2 += __shfl_xor(t2, off, kWave);
+    }
+    if (live && sub == 0) {
+        const double g[3] = {gp[3 * (size_t)p], gp[3 * (size_t)p + 1], gp[3 * (size_t)p + 2]};
+        t0 += g[0]; t1 += g[1]; t2 += g[2];
         const double* ci = Cinv + 6 * (size_t)p;
         const double e[3] = {-(ci[0] * t0 + ci[1] * t1 + ci[2] * t2), -(ci[1] * t0 + ci[3] * t1 + ci[4] * t2),
                              -(ci[2] * t0 + ci[4] * t1 + ci[5] * t2)};
@@ -844,7 +874,7 @@ void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start,
                          double* C, double* gp)
 {
     if (!n_pt) return;
-    hipLaunchKernelGGL(ba_point_reduce_kernel, dim3((n_pt + kPointBlock - 1) / kPointBlock), dim3(kPointBlock), 0, s, n_pt,
+    hipLaunchKernelGGL(ba_point_reduce_kernel, dim3(backsub_blocks(n_pt)), dim3(kPointBlock), 0, s, n_pt,
                        pt_start, pt_obs, jpr, C, gp);
 }
 
@@ -925,7 +955,7 @@ void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, cons
                     LmDiag lm, double bound_lo, double bound_hi, double* pts_out, double* dp, double* part)
 {
     if (!n_pt) return;
-    hipLaunchKernelGGL(ba_backsub_kernel, dim3((n_pt + kPointBlock - 1) / kPointBlock), dim3(kPointBlock), 0, s, n_pt, pt_start,
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3(backsub_blocks(n_pt)), dim3(kPointBlock), 0, s, n_pt, pt_start,
                        pt_obs, q_cam, jc, jpr, dc_full, Cinv, C, gp, sp, pts, lm, bound_lo, bound_hi, pts_out, dp, part);
 }
 

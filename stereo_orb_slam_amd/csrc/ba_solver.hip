@@ -465,7 +465,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     }
     h->n_chunks = (uint32_t)chunks.size();
     h->n_batches = (uint32_t)batches.size();
-    h->n_point_blocks = div_up(n_pt, kPointBlock);
+    h->n_point_blocks = backsub_blocks(n_pt);   // ba_backsub writes one partial record per workgroup
 
     // solver choice
     h->bw = 0;
