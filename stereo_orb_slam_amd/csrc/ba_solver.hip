@@ -653,8 +653,12 @@ int take_step(soslam_ba* h, double radius)
         const double* resid = nullptr;
         if (h->n_free) {
             if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
-                launch_bsr_to_dense(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->dense.p);
-                launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
+                if (dense_small_fits(h->n_free)) {
+                    launch_dense_small_solve(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->rhs(), h->dc_free.p, h->scalp());
+                } else {
+                    launch_bsr_to_dense(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->dense.p);
+                    launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
+                }
             } else if (h->use_cr && h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
                 launch_cr_factor(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->cr_ws.p, h->scalp());
                 launch_cr_solve(s, h->n_free, h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, nullptr);

@@ -41,6 +41,13 @@ void launch_dense_cholesky_solve(hipStream_t s, uint32_t n, double* dense, const
 
 size_t pcg_work_count(uint32_t n_rows);
 
+// Small systems (<= kDenseSmallRowsMax block rows: the reference's sliding windows): S expanded, factored and solved by
+// ONE workgroup in LDS, one launch.  scal[SC_LIN_STATUS] = 1 on a non-positive pivot.
+constexpr int kDenseSmallRowsMax = 22;   // 132 unknowns: 132 x 133 f64 = 140 KB of the 160 KB LDS
+bool dense_small_fits(uint32_t n_rows);
+void launch_dense_small_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
+                              const double* b, double* x, double* scal);
+
 }  // namespace soslam
 
 namespace soslam {

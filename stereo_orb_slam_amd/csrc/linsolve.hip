@@ -352,6 +352,180 @@ void launch_pcg(hipStream_t s, const BsrView& A, const double* b, double* x, dou
     hipLaunchKernelGGL(pcg_kernel, dim3(1), dim3(1024), 0, s, A, b, x, resid, work, tol, max_iter, scal);
 }
 
+// ---- small dense systems: everything in one workgroup's LDS -------------------------------------------------
+// The sliding windows of the reference (slam.cpp:121-129: at most 2 x refine_interval = 20 frames, 19 of them free)
+// give a reduced system of at most 114 unknowns.  One workgroup expands the block-sparse S into LDS, factors it by a
+// right-looking blocked Cholesky (6x6 blocks: wave 0 factors the diagonal block, one lane per panel row, one lane
+// per (block pair, row) of the trailing update) and runs both substitutions, 3 barriers per block step - no global
+// round trip between the steps, which is all the blocked multi-kernel path above spends its time on at this size.
+namespace {
+
+constexpr int kSmallThreads = 1024;
+
+__device__ __forceinline__ double small_rsqrt(double s)
+{
+    double y = __builtin_amdgcn_rsq(s);
+    y = y * (1.5 - 0.5 * s * y * y);
+    y = y * (1.5 - 0.5 * s * y * y);
+    return y;
+}
+
+__global__ __launch_bounds__(kSmallThreads) void dense_small_solve_kernel(const BsrView A, const uint32_t n_blocks,
+                                                                          const uint32_t* __restrict__ blk_row,
+                                                                          const uint32_t* __restrict__ blk_col,
+                                                                          const double* __restrict__ b, double* __restrict__ x,
+                                                                          double* __restrict__ scal)
+{
+    extern __shared__ double lds[];
+    const int nb = (int)A.n_rows, n = 6 * nb, ld = n | 1, tid = threadIdx.x;
+    double* M = lds;                    // n x ld, lower triangle becomes L
+    double* Li = M + (size_t)n * ld;    // nb x 36: inverses of the diagonal factor blocks
+    double* v = Li + nb * 36;           // n: right-hand side -> y -> x
+
+    for (int e = tid; e < n * ld; e += kSmallThreads) M[e] = 0.0;
+    if (tid < n) v[tid] = b[tid];
+    __syncthreads();
+    for (uint32_t e = tid; e < n_blocks * 36; e += kSmallThreads) {
+        const uint32_t blk = e / 36, t = e - blk * 36;
+        const int r = (int)t / 6, c = (int)t % 6;
+        const int i = 6 * (int)blk_row[blk] + r, j = 6 * (int)blk_col[blk] + c;   // blk_row <= blk_col
+        const double val = A.blocks[e];
+        M[j * ld + i] = val;            // lower triangle (and the diagonal blocks whole)
+        if (blk_row[blk] == blk_col[blk]) M[i * ld + j] = val;
+    }
+    __syncthreads();
+
+    for (int kb = 0; kb < nb; kb++) {
+        const int k0 = 6 * kb;
+        if (tid < 64) {
+            // diagonal block: L_kk and its inverse, lane 0 of wave 0 (a 6x6 chain; the other lanes would only repeat it)
+            if (tid == 0) {
+                double L[6][6], I[6][6];
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+#pragma unroll
+                    for (int i = j; i < 6; i++) {
+                        double sacc = M[(k0 + i) * ld + k0 + j];
+#pragma unroll
+                        for (int k = 0; k < j; k++) sacc -= L[i][k] * L[j][k];
+                        if (i == j) {
+                            ok = ok && (sacc > 0.0);
+                            const double y = small_rsqrt(sacc);
+                            I[j][j] = y;
+                            L[j][j] = sacc * y;
+                        } else {
+                            L[i][j] = sacc * I[j][j];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+#pragma unroll
+                    for (int i = j + 1; i < 6; i++) {
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int k = j; k < i; k++) sacc -= L[i][k] * I[k][j];
+                        I[i][j] = sacc * I[i][i];
+                    }
+                if (!ok) scal[SC_LIN_STATUS] = 1.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        M[(k0 + i) * ld + k0 + j] = j <= i ? L[i][j] : 0.0;
+                        Li[kb * 36 + i * 6 + j] = j <= i ? I[i][j] : 0.0;
+                    }
+            }
+        }
+        __syncthreads();
+        // panel: rows below the diagonal block, A_ik <- A_ik L_kk^-T
+        const int rows_below = n - k0 - 6;
+        if (tid < rows_below) {
+            double* a = M + (size_t)(k0 + 6 + tid) * ld + k0;
+            const double* I = Li + kb * 36;
+            const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
+            a[0] = a0 * I[0];
+            a[1] = a0 * I[6] + a1 * I[7];
+            a[2] = a0 * I[12] + a1 * I[13] + a2 * I[14];
+            a[3] = a0 * I[18] + a1 * I[19] + a2 * I[20] + a3 * I[21];
+            a[4] = a0 * I[24] + a1 * I[25] + a2 * I[26] + a3 * I[27] + a4 * I[28];
+            a[5] = a0 * I[30] + a1 * I[31] + a2 * I[32] + a3 * I[33] + a4 * I[34] + a5 * I[35];
+        }
+        __syncthreads();
+        // trailing update of the lower triangle: A_ij -= L_ik L_jk^T, one lane per (row i, block column jb <= ib)
+        const int nbr = nb - 1 - kb;                       // block rows below
+        const int n_items = rows_below * nbr;              // (row, jb) with jb <= row's block filtered below
+        for (int item = tid; item < n_items; item += kSmallThreads) {
+            const int jb = item / rows_below, ri = item - jb * rows_below;   // ri: row below the pivot block
+            if (jb * 6 > ri) continue;                     // only the lower triangle (by block)
+            const double* li = M + (size_t)(k0 + 6 + ri) * ld + k0;
+            const double l0 = li[0], l1 = li[1], l2 = li[2], l3 = li[3], l4 = li[4], l5 = li[5];
+            double* tgt = M + (size_t)(k0 + 6 + ri) * ld + k0 + 6 + jb * 6;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double* lj = M + (size_t)(k0 + 6 + jb * 6 + c) * ld + k0;
+                tgt[c] -= l0 * lj[0] + l1 * lj[1] + l2 * lj[2] + l3 * lj[3] + l4 * lj[4] + l5 * lj[5];
+            }
+        }
+        __syncthreads();
+    }
+
+    // forward: y_k = L_kk^-1 v_k, then v_i -= L_ik y_k for the rows below
+    for (int kb = 0; kb < nb; kb++) {
+        const int k0 = 6 * kb;
+        double yk = 0.0;
+        if (tid < 6) {
+            const double* I = Li + kb * 36 + tid * 6;
+#pragma unroll
+            for (int c = 0; c < 6; c++) yk += I[c] * v[k0 + c];
+        }
+        __syncthreads();
+        if (tid < 6) v[k0 + tid] = yk;
+        __syncthreads();
+        const int row = k0 + 6 + tid;
+        if (row < n) {
+            const double* l = M + (size_t)row * ld + k0;
+            v[row] -= l[0] * v[k0] + l[1] * v[k0 + 1] + l[2] * v[k0 + 2] + l[3] * v[k0 + 3] + l[4] * v[k0 + 4] + l[5] * v[k0 + 5];
+        }
+        __syncthreads();
+    }
+    // backward: x_k = L_kk^-T y_k, then v_i -= L_ki^T x_k for the rows above
+    for (int kb = nb - 1; kb >= 0; kb--) {
+        const int k0 = 6 * kb;
+        double xk = 0.0;
+        if (tid < 6) {
+            const double* I = Li + kb * 36;
+#pragma unroll
+            for (int c = 0; c < 6; c++) xk += I[c * 6 + tid] * v[k0 + c];
+        }
+        __syncthreads();
+        if (tid < 6) v[k0 + tid] = xk;
+        __syncthreads();
+        if (tid < k0) {
+            const double* l = M + (size_t)k0 * ld + tid;   // column tid of the block row k
+            v[tid] -= l[0] * v[k0] + l[ld] * v[k0 + 1] + l[2 * ld] * v[k0 + 2] + l[3 * ld] * v[k0 + 3] + l[4 * ld] * v[k0 + 4] +
+                      l[5 * ld] * v[k0 + 5];
+        }
+        __syncthreads();
+    }
+    if (tid < n) x[tid] = v[tid];
+}
+
+}  // namespace
+
+bool dense_small_fits(uint32_t n_rows) { return n_rows >= 1 && n_rows <= (uint32_t)kDenseSmallRowsMax; }
+
+void launch_dense_small_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
+                              const double* b, double* x, double* scal)
+{
+    if (!A.n_rows) return;
+    const size_t n = 6 * (size_t)A.n_rows, ld = n | 1;
+    const size_t lds = sizeof(double) * (n * ld + (size_t)A.n_rows * 36 + n);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_small_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dense_small_solve_kernel, dim3(1), dim3(kSmallThreads), lds, s, A, n_blocks, blk_row, blk_col, b, x, scal);
+}
+
 void launch_bsr_to_dense(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row,
                          const uint32_t* blk_col, double* dense)
 {
