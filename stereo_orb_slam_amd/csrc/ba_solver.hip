@@ -181,10 +181,22 @@ void collect_stage_times(soslam_ba* h, soslam_ba_summary* s)
 
 // ---- index construction ------------------------------------------------------------------------------
 
+// SOSLAM_SETUP_TIMING=1 prints where set_problem spends its host time (development aid)
+#define SETUP_MARK(label)                                                                        \
+    do {                                                                                         \
+        if (setup_timing) {                                                                      \
+            const double t_now = now_sec();                                                      \
+            std::fprintf(stderr, "[setup] %-14s %8.3f ms\n", label, 1e3 * (t_now - t_mark));     \
+            t_mark = t_now;                                                                      \
+        }                                                                                        \
+    } while (0)
+
 int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, const uint32_t* ocam,
                   const uint32_t* opt_, const float* ouv, const uint8_t* fixed)
 {
     const double t0 = now_sec();
+    const bool setup_timing = std::getenv("SOSLAM_SETUP_TIMING") != nullptr;
+    double t_mark = t0;
     hipStream_t s = h->stream;
     for (uint32_t k = 0; k < n_obs; k++)
         if (ocam[k] >= n_cam || opt_[k] >= n_pt) {
@@ -200,6 +212,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         if (!(fixed && fixed[c])) h->h_cam_free[c] = (int32_t)nf++;
     h->n_free = nf;
 
+    SETUP_MARK("begin");
     // internal point order: by (first camera, last camera, caller id) so that neighbouring points share
     // their camera window (the Schur kernel's chunks) and a camera bucket reads near-contiguous points
     std::vector<uint32_t> pmin(n_pt, UINT32_MAX), pmax(n_pt, 0), pcnt(n_pt, 0), pfree(n_pt, 0);
@@ -216,26 +229,42 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     for (uint32_t p = 0; p < n_pt; p++)
         if (pfree[p] > kWindowMax || pcnt[p] > (uint32_t)kBatchObs) { is_long[p] = 1; n_long++; }
     const uint32_t n_short = n_pt - n_long;
+    // order (long flag, first camera, last camera, caller id): two stable counting sorts over the cameras, then a
+    // stable partition - linear in the points, no comparator calls
     h->pt_int2user.resize(n_pt);
-    std::iota(h->pt_int2user.begin(), h->pt_int2user.end(), 0u);
-    std::sort(h->pt_int2user.begin(), h->pt_int2user.end(), [&](uint32_t a, uint32_t b) {
-        if (is_long[a] != is_long[b]) return is_long[a] < is_long[b];
-        if (pmin[a] != pmin[b]) return pmin[a] < pmin[b];
-        if (pmax[a] != pmax[b]) return pmax[a] < pmax[b];
-        return a < b;
-    });
+    {
+        std::vector<uint32_t> tmp(n_pt), cnt(n_cam + 2);
+        auto counting_pass = [&](const std::vector<uint32_t>& key, const uint32_t* in, uint32_t* out, bool identity_in) {
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (uint32_t i = 0; i < n_pt; i++) cnt[std::min(key[identity_in ? i : in[i]], n_cam) + 1]++;   // unobserved points: key n_cam
+            for (uint32_t c = 0; c <= n_cam; c++) cnt[c + 1] += cnt[c];
+            for (uint32_t i = 0; i < n_pt; i++) {
+                const uint32_t id = identity_in ? i : in[i];
+                out[cnt[std::min(key[id], n_cam)]++] = id;
+            }
+        };
+        counting_pass(pmax, nullptr, tmp.data(), true);                        // least significant key first
+        counting_pass(pmin, tmp.data(), h->pt_int2user.data(), false);
+        std::stable_partition(h->pt_int2user.begin(), h->pt_int2user.end(), [&](uint32_t id) { return !is_long[id]; });
+    }
     h->pt_user2int.resize(n_pt);
     for (uint32_t i = 0; i < n_pt; i++) h->pt_user2int[h->pt_int2user[i]] = i;
 
+    SETUP_MARK("point order");
     // camera-major observation order: (camera, internal point)
+    // (camera, internal point, caller index): stable counting sort by internal point, then by camera
     h->obs_int2user.resize(n_obs);
-    std::iota(h->obs_int2user.begin(), h->obs_int2user.end(), 0u);
-    std::sort(h->obs_int2user.begin(), h->obs_int2user.end(), [&](uint32_t a, uint32_t b) {
-        if (ocam[a] != ocam[b]) return ocam[a] < ocam[b];
-        const uint32_t pa = h->pt_user2int[opt_[a]], pb = h->pt_user2int[opt_[b]];
-        if (pa != pb) return pa < pb;
-        return a < b;
-    });
+    {
+        std::vector<uint32_t> tmp(n_obs), cnt(std::max(n_pt, n_cam) + 1);
+        std::fill(cnt.begin(), cnt.begin() + n_pt + 1, 0u);
+        for (uint32_t k = 0; k < n_obs; k++) cnt[h->pt_user2int[opt_[k]] + 1]++;
+        for (uint32_t p = 0; p < n_pt; p++) cnt[p + 1] += cnt[p];
+        for (uint32_t k = 0; k < n_obs; k++) tmp[cnt[h->pt_user2int[opt_[k]]]++] = k;
+        std::fill(cnt.begin(), cnt.begin() + n_cam + 1, 0u);
+        for (uint32_t k = 0; k < n_obs; k++) cnt[ocam[k] + 1]++;
+        for (uint32_t c = 0; c < n_cam; c++) cnt[c + 1] += cnt[c];
+        for (uint32_t i = 0; i < n_obs; i++) h->obs_int2user[cnt[ocam[tmp[i]]]++] = tmp[i];
+    }
     std::vector<float4> uv(n_obs);
     std::vector<uint32_t> v_obs_pt(n_obs), v_obs_cam(n_obs);
     std::vector<uint32_t> cam_start(n_cam + 1, 0);
@@ -248,6 +277,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     }
     for (uint32_t c = 0; c < n_cam; c++) cam_start[c + 1] += cam_start[c];
 
+    SETUP_MARK("obs order");
     // tiles: <= kTileObs observations of one camera each
     std::vector<Tile> tiles;
     std::vector<uint32_t> cam_tile_start(n_cam + 1, 0);
@@ -273,12 +303,22 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         }
     }
 
+    SETUP_MARK("tiles+lists");
     // block-sparse pattern of the reduced camera matrix: pairs of free cameras that share a point
     std::vector<std::vector<uint32_t>> rows(nf);
     uint32_t max_track = 0;
     {
+        // up to 4096 free cameras the pairs are marked in an upper-triangular bitmap (2 MB at most) and the rows read
+        // off it; beyond that they are collected per row and sorted
+        const bool use_bitmap = nf <= 4096;
+        const size_t words_per_row = (nf + 63) / 64;
+        std::vector<uint64_t> bits(use_bitmap ? (size_t)nf * words_per_row : 0, 0);
+        auto mark = [&](uint32_t a, uint32_t b) {   // a <= b
+            if (use_bitmap) bits[(size_t)a * words_per_row + (b >> 6)] |= 1ull << (b & 63);
+            else rows[a].push_back(b);
+        };
         std::vector<uint32_t> fc;
-        for (uint32_t f = 0; f < nf; f++) rows[f].push_back(f);
+        for (uint32_t f = 0; f < nf; f++) mark(f, f);
         for (uint32_t p = 0; p < n_pt; p++) {
             fc.clear();
             for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
@@ -287,7 +327,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             }
             if (p < n_short) max_track = std::max<uint32_t>(max_track, (uint32_t)fc.size());
             for (size_t a = 0; a < fc.size(); a++)
-                for (size_t b = a + 1; b < fc.size(); b++) rows[fc[a]].push_back(fc[b]);
+                for (size_t b = a + 1; b < fc.size(); b++) mark(fc[a], fc[b]);
         }
         for (const auto& pr : h->covis) {
             if (pr.first >= n_cam || pr.second >= n_cam) {
@@ -296,11 +336,22 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             }
             const int32_t fa = h->h_cam_free[pr.first], fb = h->h_cam_free[pr.second];
             if (fa < 0 || fb < 0) continue;
-            rows[std::min(fa, fb)].push_back((uint32_t)std::max(fa, fb));
+            mark((uint32_t)std::min(fa, fb), (uint32_t)std::max(fa, fb));
         }
-        for (auto& r : rows) {
-            std::sort(r.begin(), r.end());
-            r.erase(std::unique(r.begin(), r.end()), r.end());
+        if (use_bitmap) {
+            for (uint32_t f = 0; f < nf; f++)
+                for (size_t w = f >> 6; w < words_per_row; w++) {
+                    uint64_t m = bits[(size_t)f * words_per_row + w];
+                    while (m) {
+                        rows[f].push_back((uint32_t)(w * 64 + (size_t)__builtin_ctzll(m)));
+                        m &= m - 1;
+                    }
+                }
+        } else {
+            for (auto& r : rows) {
+                std::sort(r.begin(), r.end());
+                r.erase(std::unique(r.begin(), r.end()), r.end());
+            }
         }
     }
     h->kmax = max_track > 16 ? 32 : 16;
@@ -342,6 +393,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         }
     }
 
+    SETUP_MARK("pattern");
     // Schur chunks: consecutive points whose free cameras fit kmax local slots; batches of <= 128 obs
     const int K = h->kmax;
     const uint32_t chunk_pts_max = std::max<uint32_t>(32, std::min<uint32_t>(1024, n_pt / 512 + 1));
@@ -467,6 +519,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     h->n_batches = (uint32_t)batches.size();
     h->n_point_blocks = backsub_blocks(n_pt);   // ba_backsub writes one partial record per workgroup
 
+    SETUP_MARK("chunks");
     // solver choice
     h->bw = 0;
     for (uint32_t b = 0; b < h->n_blocks; b++) h->bw = std::max<int>(h->bw, (int)(h->h_blk_col[b] - h->h_blk_row[b]));
@@ -481,6 +534,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     }
     h->pcg_band = h->solver == SOSLAM_SOLVER_PCG && band_fits;
 
+    SETUP_MARK("solver choice");
     // uploads
     SOSLAM_CHECK(h->uv.upload(uv, s));
     SOSLAM_CHECK(h->obs_pt.upload(v_obs_pt, s));
@@ -515,6 +569,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->blk_row.upload(h->h_blk_row, s));
     SOSLAM_CHECK(h->blk_col.upload(h->h_blk_col, s));
 
+    SETUP_MARK("uploads");
     // work buffers
     for (int i = 0; i < 2; i++) {
         SOSLAM_CHECK(h->cams[i].alloc((size_t)n_cam * 6));
@@ -573,6 +628,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
     h->have_problem = true;
     h->have_state = false;
+    SETUP_MARK("alloc+sync");
     h->setup_seconds = now_sec() - t0;
     return SOSLAM_OK;
 }
