@@ -534,3 +534,19 @@ def test_empty_and_ragged_problems(gpu, oracle_lib, prob1):
     ocams, opts_, osum, _ = _oracle_solve(oracle_lib, one, max_iterations=20)
     assert summ.final_cost <= summ.initial_cost
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+
+
+@pytest.mark.parametrize("n_cam", [20, 23, 24])
+def test_dense_solver_sizes_around_the_one_workgroup_limit(gpu, oracle_lib, n_cam):
+    """The reference's sliding window (20 frames, 19 free) and the sizes either side of the 22-camera limit of the
+    one-workgroup dense solve: 22 free cameras still take it, 23 take the blocked multi-kernel path."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, n_cam=n_cam, n_pt=1500, track_mode=0, track_len=min(n_cam, 18), spacing=0.2)
+    ref = oracle_lib.step(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, 1e4)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=1)) as h:
+        h.load(p)
+        h.debug_step(1e4)
+        dc, dp, sc = h.debug_read(L.DBG_STEP_CAM), h.debug_read(L.DBG_STEP_POINT), h.debug_read(L.DBG_STEP_SCALARS)
+    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-6, atol=1e-9 * np.abs(ref["dc"]).max())
+    np.testing.assert_allclose(dp, ref["dp"], rtol=1e-6, atol=1e-9 * np.abs(ref["dp"]).max())
+    assert sc[1] == pytest.approx(ref["model_cost_change"], rel=1e-7) and sc[5] == 0
