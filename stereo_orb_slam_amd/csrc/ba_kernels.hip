@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void ba_cam_damp_kernel(uint32_t n_free, const
 }
 
 // candidate cameras, full-length camera step, camera share of the step scalars (one workgroup)
-__global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, const int32_t* __restrict__ cam_free,
+__global__ __launch_bounds__(1024) void ba_cam_update_kernel(uint32_t n_cam, const int32_t* __restrict__ cam_free,
                                                             const double* __restrict__ cams,
                                                             const double* __restrict__ dc_free,
                                                             const double* __restrict__ lc, const double* __restrict__ gc_red,
@@ -709,9 +709,9 @@ __global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, cons
                                                             double* __restrict__ cams_out, double* __restrict__ dc_full,
                                                             double* __restrict__ scal)
 {
-    __shared__ double red[4 * 5];
+    __shared__ double red[16 * 5];
     double mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_cam * 6; i += 256) {
+    for (uint32_t i = threadIdx.x; i < n_cam * 6; i += 1024) {
         const uint32_t c = i / 6, a = i % 6;
         const int32_t f = cam_free[c];
         const double x = cams[i];
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, cons
     __syncthreads();
     if (threadIdx.x == 0) {
         double a = 0, b = 0, c = 0, d = 0, e = 0;
-        for (int w = 0; w < 4; w++) { a += red[w * 5]; b += red[w * 5 + 1]; c += red[w * 5 + 2]; d += red[w * 5 + 3]; e = fmax(e, red[w * 5 + 4]); }
+        for (int w = 0; w < 16; w++) { a += red[w * 5]; b += red[w * 5 + 1]; c += red[w * 5 + 2]; d += red[w * 5 + 3]; e = fmax(e, red[w * 5 + 4]); }
         scal[SC_MCC_CAM] = a; scal[SC_STEP2_CAM] = b; scal[SC_X2_CAM] = c; scal[SC_GDOT_CAM] = d; scal[SC_GMAX_CAM] = e;
     }
 }
@@ -945,7 +945,7 @@ void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, c
                        const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid,
                        double* cams_out, double* dc_full, double* scal)
 {
-    hipLaunchKernelGGL(ba_cam_update_kernel, dim3(1), dim3(256), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red, lin_resid,
+    hipLaunchKernelGGL(ba_cam_update_kernel, dim3(1), dim3(1024), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red, lin_resid,
                        cams_out, dc_full, scal);
 }
 

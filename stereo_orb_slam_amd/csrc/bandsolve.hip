@@ -464,18 +464,37 @@ __global__ __launch_bounds__(1024) void pcg_band_init_kernel(uint32_t n, const d
 }
 
 // q = S p over many workgroups, per-workgroup partial p.q
+// q = S p and the partial p.q: four lanes per scalar row share its block entries (the kernel is a latency-bound gather
+// of 48-byte block rows), fixed butterfly, then the fixed block sum
+constexpr int kMatvecLanes = 4;
 __global__ __launch_bounds__(256) void pcg_band_matvec_kernel(const BsrView A, const double* __restrict__ p, double* __restrict__ q,
                                                               double* __restrict__ part, const double* __restrict__ state)
 {
     __shared__ double red[4];
     if (state[PS_DONE] != 0.0) return;
     const uint32_t n = A.n_rows * 6;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    double pq = 0.0;
+    const uint32_t i = (blockIdx.x * 256 + threadIdx.x) / kMatvecLanes, sub = threadIdx.x % kMatvecLanes;
+    double s = 0.0;
     if (i < n) {
-        const double qi = bsr_row_dot(A, i, p);
-        q[i] = qi;
-        pq = p[i] * qi;
+        const uint32_t f = i / 6, a = i % 6;
+        for (uint32_t e = A.row_ptr[f] + sub; e < A.row_ptr[f + 1]; e += kMatvecLanes) {
+            const double* B = A.blocks + 36 * (size_t)A.ent_blk[e];
+            const double* x = p + 6 * (size_t)A.ent_col[e];
+            if (A.ent_trans[e]) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s += B[c * 6 + a] * x[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s += B[a * 6 + c] * x[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < kMatvecLanes; off <<= 1) s += __shfl_xor(s, off, 64);
+    double pq = 0.0;
+    if (i < n && sub == 0) {
+        q[i] = s;
+        pq = p[i] * s;
     }
     pq = block_sum(pq, red);
     if (threadIdx.x == 0) part[blockIdx.x] = pq;
@@ -518,7 +537,8 @@ __global__ __launch_bounds__(1024) void pcg_band_update_kernel(uint32_t n, uint3
 }  // namespace
 
 size_t band_count(uint32_t n_rows, int bw) { return (size_t)n_rows * (bw + 1) * 36; }
-size_t pcg_band_work_count(uint32_t n_rows) { return (size_t)n_rows * 6 * 3 + PS_COUNT + (n_rows * 6 + 255) / 256 + 8; }
+static uint32_t pcg_band_matvec_blocks(uint32_t n) { return (n * kMatvecLanes + 255) / 256; }
+size_t pcg_band_work_count(uint32_t n_rows) { return (size_t)n_rows * 6 * 3 + PS_COUNT + pcg_band_matvec_blocks(n_rows * 6) + 8; }
 
 void launch_bsr_to_band(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row,
                         const uint32_t* blk_col, int bw, double* band)
@@ -549,7 +569,7 @@ void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band
                      const double* b, double* x, double* resid, double* work, double tol, int max_rounds, double* scal)
 {
     if (!A.n_rows) return;
-    const uint32_t n = A.n_rows * 6, n_wg = (n + 255) / 256;
+    const uint32_t n = A.n_rows * 6, n_wg = pcg_band_matvec_blocks(n);
     double* p = work;
     double* z = work + n;
     double* q = work + 2 * (size_t)n;
@@ -569,7 +589,7 @@ void launch_pcg_cr(hipStream_t s, const BsrView& A, int bw, double* cr_ws, const
                    double tol, int max_rounds, double* scal)
 {
     if (!A.n_rows) return;
-    const uint32_t n = A.n_rows * 6, n_wg = (n + 255) / 256;
+    const uint32_t n = A.n_rows * 6, n_wg = pcg_band_matvec_blocks(n);
     double* p = work;
     double* z = work + n;
     double* q = work + 2 * (size_t)n;
