@@ -781,10 +781,14 @@ int take_step(soslam_ba* h, double radius)
     }
     SOSLAM_HIP_CHECK(hipGetLastError());
     // The band factor is exact, so one PCG round (= a direct solve plus the true residual) normally meets the
-    // tolerance.  Rounds are enqueued without host checks; if this solve fell short - the step is still a valid
-    // inexact step, its residual enters the model cost change - later solves enqueue one round more.
-    if (h->use_cr && h->pcg_band && h->n_free && h->host_scal[SC_LIN_RESID] > h->opt.pcg_tolerance && h->cr_rounds < 4)
-        h->cr_rounds++;
+    // tolerance.  Rounds are enqueued without host checks: if this solve fell short - the step is still a valid
+    // inexact step, its residual enters the model cost change - the next solve enqueues one round more; if it was
+    // done before its last round, the next one enqueues only as many as were used.
+    if (h->use_cr && h->pcg_band && h->n_free) {
+        const int used = (int)h->host_scal[SC_LIN_ITERS];
+        if (h->host_scal[SC_LIN_RESID] > h->opt.pcg_tolerance) h->cr_rounds = std::min(h->cr_rounds + 1, 4);
+        else if (used >= 1 && used < h->cr_rounds) h->cr_rounds = used;
+    }
     return SOSLAM_OK;
 }
 
