@@ -64,7 +64,8 @@ __device__ __forceinline__ void pose_rotation(const double* __restrict__ cam, Po
 
 // Per-camera quantities every observation of that camera needs, computed once per linearisation by
 // ba_pose_prepare and read through scalar loads (one camera per workgroup => wave-uniform):
-//   R (9)  rotation of the branch taken;  M (9) = R Jr so that d(R x)/dw = -[R x]x M;  t (3);  small flag.
+//   R (9)  rotation of the branch taken;  M (9) with d(R x)/dw = -[v]x M, where v = R x and M = R Jr on the Rodrigues
+//   branch, v = x and M = I on the first-order branch;  t (3);  small flag.
 constexpr int kPoseStride = 24;
 struct PosePre {
     double R[9];
@@ -88,7 +89,8 @@ __device__ __forceinline__ void pose_prepare(const double* __restrict__ cam, dou
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++)
-            out[9 + i * 3 + j] = p.R[i * 3] * Jr[j] + p.R[i * 3 + 1] * Jr[3 + j] + p.R[i * 3 + 2] * Jr[6 + j];
+            out[9 + i * 3 + j] = p.small ? (i == j ? 1.0 : 0.0)   // first-order branch: d(x + w x x)/dw = -[x]x, i.e. M = I with v = x
+                                         : p.R[i * 3] * Jr[j] + p.R[i * 3 + 1] * Jr[3 + j] + p.R[i * 3 + 2] * Jr[6 + j];
     out[18] = cam[3]; out[19] = cam[4]; out[20] = cam[5];
     out[21] = p.small ? 1.0 : 0.0;
     out[22] = 0.0; out[23] = 0.0;
@@ -150,7 +152,8 @@ __device__ __forceinline__ double residual_cost(const PosePre& pr, const double*
 // corrected residual r[4], J_c[24] (4x6 row-major), J_p[12] (4x3 row-major); returns rho(|r|^2)
 __device__ __forceinline__ double residual_jacobian(const PosePre& pr, const double* x, const float4 uv, const Proj& P,
                                                     double delta, bool cam_fixed, double* __restrict__ r,
-                                                    double* __restrict__ jc, double* __restrict__ jp)
+                                                    double* __restrict__ jc, double* __restrict__ jp,
+                                                    double* __restrict__ a_out = nullptr)
 {
     double yr[3], y[3];
 #pragma unroll
@@ -166,27 +169,22 @@ __device__ __forceinline__ double residual_jacobian(const PosePre& pr, const dou
     huber(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], delta, rho0, rho1);
     const double sw = sqrt(rho1);
 
-    // D = d(R x)/dw, 3x3
+    // D = d(R x)/dw = -[v]x M, 3x3 (v = x, M = I on the first-order branch; v = R x, M = R Jr otherwise)
     double D[9];
-    if (pr.small) {
-        // y = x + w x x  =>  dy/dw = -[x]x
-        D[0] = 0.0;   D[1] = x[2];  D[2] = -x[1];
-        D[3] = -x[2]; D[4] = 0.0;   D[5] = x[0];
-        D[6] = x[1];  D[7] = -x[0]; D[8] = 0.0;
-    } else {
-        // -R [x]x Jr = -[R x]x (R Jr) = -[yr]x M with M = R Jr from ba_pose_prepare
+    {
+        const double v0 = pr.small ? x[0] : yr[0], v1 = pr.small ? x[1] : yr[1], v2 = pr.small ? x[2] : yr[2];
         const double* M = pr.M;
-        // D = -[yr]x M : row i of [yr]x M = yr x M_col... ([a]x M)_ij = a_{i+1} M_{i+2,j} - a_{i+2} M_{i+1,j}
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            D[0 * 3 + j] = -(yr[1] * M[2 * 3 + j] - yr[2] * M[1 * 3 + j]);
-            D[1 * 3 + j] = -(yr[2] * M[0 * 3 + j] - yr[0] * M[2 * 3 + j]);
-            D[2 * 3 + j] = -(yr[0] * M[1 * 3 + j] - yr[1] * M[0 * 3 + j]);
+            D[0 * 3 + j] = -(v1 * M[2 * 3 + j] - v2 * M[1 * 3 + j]);
+            D[1 * 3 + j] = -(v2 * M[0 * 3 + j] - v0 * M[2 * 3 + j]);
+            D[2 * 3 + j] = -(v0 * M[1 * 3 + j] - v1 * M[0 * 3 + j]);
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const double a0 = A[i * 3] * sw, a1 = A[i * 3 + 1] * sw, a2 = A[i * 3 + 2] * sw;
+        if (a_out) { a_out[i * 3] = a0; a_out[i * 3 + 1] = a1; a_out[i * 3 + 2] = a2; }
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             jc[i * 6 + j] = cam_fixed ? 0.0 : a0 * D[j] + a1 * D[3 + j] + a2 * D[6 + j];
@@ -198,6 +196,51 @@ __device__ __forceinline__ double residual_jacobian(const PosePre& pr, const dou
         r[i] *= sw;
     }
     return rho0;
+}
+
+// ---- compact Jacobian rows -----------------------------------------------------------------------------
+// ba_linearize stores per observation only A (4x3: the loss-corrected derivative of the four image coordinates with
+// respect to the camera-frame point) and the corrected residual r: 16 doubles.  With the camera's R, M and the point x
+//     J_p = A R                              (4x3)
+//     J_c = [ A D | A ],  D = -[v]x M        (4x6; v = R x, or x on the first-order branch)
+// so every consumer rebuilds what it needs from 128 B per observation instead of reading 320 B.  The kernels that
+// reduce per point go one step further and keep M out of the per-observation work: with
+//     W~ = [ [v]x (A^T A R) ; A^T A R ] (6x3)      one has    J_c^T J_p = T W~,   T = blockdiag(M^T, I)
+//     (D^T = (-[v]x M)^T = M^T [v]x)
+// and T is applied once per camera block after the sums (ba_schur_reduce), or folded into the step (ba_cam_update
+// hands ba_backsub  w = M dc_rot  per camera:  J_c dc = A (w x v + dc_t)).
+__device__ __forceinline__ void compact_v(const double* __restrict__ R, bool small, const double* __restrict__ x, double* __restrict__ v)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) v[i] = small ? x[i] : R[i * 3] * x[0] + R[i * 3 + 1] * x[1] + R[i * 3 + 2] * x[2];
+}
+
+// J_p = A R  (row-major 4x3)
+__device__ __forceinline__ void compact_jp(const double* __restrict__ A, const double* __restrict__ R, double* __restrict__ jp)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) jp[i * 3 + j] = A[i * 3] * R[j] + A[i * 3 + 1] * R[3 + j] + A[i * 3 + 2] * R[6 + j];
+}
+
+// W~ (6x3 row-major): rows 3..5 = A^T J_p, rows 0..2 = [v]x (A^T J_p) = v x column
+__device__ __forceinline__ void compact_wt(const double* __restrict__ A, const double* __restrict__ jp, const double* __restrict__ v,
+                                           double* __restrict__ w)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            w[(3 + r) * 3 + c] = A[r] * jp[c] + A[3 + r] * jp[3 + c] + A[6 + r] * jp[6 + c] + A[9 + r] * jp[9 + c];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double z0 = w[9 + c], z1 = w[12 + c], z2 = w[15 + c];     // column c of A^T J_p
+        // [v]x z = v x z
+        w[0 + c] = v[1] * z2 - v[2] * z1;
+        w[3 + c] = v[2] * z0 - v[0] * z2;
+        w[6 + c] = v[0] * z1 - v[1] * z0;
+    }
 }
 
 // inverse of a symmetric positive definite 3x3 (xx xy xz yy yz zz); ok=false when not positive definite

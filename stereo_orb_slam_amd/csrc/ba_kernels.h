@@ -13,8 +13,7 @@ namespace soslam {
 constexpr int kTileObs = 1024;       // observations per linearize/cost workgroup (one camera per tile)
 constexpr int kTileThreads = 256;    // lanes per tile: up to 4 observations each
 constexpr int kTileVals = 28;        // 21 (J_c^T J_c upper) + 6 (J_c^T r) + 1 (rho)
-constexpr int kJcRow = 24;           // f64 per observation in the J_c array (4x6 row-major, 192 B)
-constexpr int kJprRow = 16;          // f64 per observation in the [J_p | r] array (4x3 row-major + 4, 128 B)
+constexpr int kArRow = 16;            // f64 per observation in the compact Jacobian array [A (4x3 row-major) | r (4)], 128 B
 constexpr int kBatchObs = 128;       // observations staged per Schur batch
 // points per Schur batch: the batch's point columns (3 each) are the k dimension of the window GEMM, and two
 // [3 PB][6 KMAX + 1] f64 images must fit LDS next to the staged rows
@@ -69,7 +68,7 @@ void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, doub
 
 void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
                       const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
-                      double* jc, double* jpr, double* tile_part);
+                      double* ar, double* tile_part);
 
 void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
                  const double* campre, const double* pts, const Proj& P, double delta, double* cost_part);
@@ -82,15 +81,16 @@ void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
                        const double* tile_part, double* B /* [F][36] */, double* gc /* [F][6] */);
 
-void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const double* jpr,
-                         double* C /* [n_pt][6] */, double* gp /* [n_pt][3] */);
+void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
+                         const double* ar, const double* campre, double* C, double* gp);
 
 void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacobi, double* sp);
 
 // chunk windows into per-chunk slabs (chunk_slab[c] = offset of chunk c, layout [pair][36] then [camera][6])
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
-                  const uint32_t* chunk_slab, const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* jc,
-                  const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* slab,
+                  const uint32_t* chunk_slab, const uint32_t* chunk_cam /* [n_chunks][kmax] camera of each window slot */,
+                  const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* ar, const double* campre,
+                  const double* pts, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* slab,
                   double* scal);
 
 // Multi-rank jobs: a rank whose point elimination failed (SC_SCHUR_STATUS) turns its share of the candidate cost
@@ -99,27 +99,27 @@ void launch_status_poison(hipStream_t s, double* scal);
 
 // long-track points (see LongPoint): damped point block inverse, W / Y of every free-camera observation into
 // wy[lo][36] and Y g into the slab at lo_cam_off[lo]; then Y_a W_b^T of every listed pair into the slab at pair_off
-void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts, const uint32_t* lo_row, const uint32_t* lo_cam_off,
-                       uint32_t n_pairs, const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* pair_off, const double* jc,
-                       const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* wy,
-                       double* slab, double* scal);
+void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts, const uint32_t* lo_row, const uint32_t* lo_cam,
+                       const uint32_t* lo_cam_off, uint32_t n_pairs, const uint32_t* pair_a, const uint32_t* pair_b,
+                       const uint32_t* pair_off, const double* ar, const double* campre, const double* pts, const double* C,
+                       const double* gp, const double* sp, LmDiag lm, double* Cinv, double* wy, double* slab, double* scal);
 
 // S = B - sum(slabs), rhs = -g_c + sum(slab rhs parts) through host-built contribution lists (fixed order);
 // exports diag(B) and g_c next to them for the all-reduce
 void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, const uint32_t* blk_ptr, const uint32_t* blk_off,
                          const uint32_t* cam_ptr, const uint32_t* cam_off, const uint32_t* blk_row, const uint32_t* blk_col,
-                         const double* slab, const double* B, const double* gc, double* S, double* rhs, double* diagB,
-                         double* gc_red);
+                         const uint32_t* free_cam /* camera of each free index */, const double* campre, const double* slab,
+                         const double* B, const double* gc, double* S, double* rhs, double* diagB, double* gc_red);
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,
                      LmDiag lm, const int32_t* diag_block, double* S, double* lc);
 
 void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams,
-                       const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid,
-                       double* cams_out, double* dc_full, double* scal);
+                       const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid, const double* campre,
+                       double* cams_out, double* dc_full, double* dcw /* [n_cam][6]: M dc_rot | dc_t */, double* scal);
 
 void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
-                    const double* jc, const double* jpr, const double* dc_full,
+                    const double* ar, const double* campre, const double* dcw,
                     const double* Cinv, const double* C, const double* gp, const double* sp, const double* pts,
                     LmDiag lm, double bound_lo, double bound_hi, double* pts_out, double* dp, double* part);
 

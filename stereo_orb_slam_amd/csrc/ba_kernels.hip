@@ -50,28 +50,27 @@ __global__ __launch_bounds__(64) void ba_pose_prepare_kernel(uint32_t n_cam, con
 // camera's rotation block is workgroup-uniform and arrives through scalar loads.  Each lane evaluates up
 // to 4 observations (strided by 256, coalesced), writes their corrected Jacobian rows, and keeps its share
 // of J_c^T J_c / J_c^T r / rho in registers; one wave-shuffle + LDS reduction per workgroup.
-// Algorithmic bytes per observation: 16 (uv) + 4 (point id) + 24 (point) in, 192 + 128 out = 364
-// (SURVEY.md section 8(d) counts 368 with the second index).
+// Only the compact row [A | r] (ba_device.h) leaves the kernel: 16 (uv) + 4 (point id) + 24 (point) in, 128 out
+// = 172 B per observation ("fused" in the sense of SURVEY.md section 8(d): J_c and J_p are never written).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
     const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
     const double* __restrict__ campre, const double* __restrict__ pts, const int32_t* __restrict__ cam_free,
-    const Proj P, const double delta, double* __restrict__ jc_out, double* __restrict__ jpr_out,
-    double* __restrict__ tile_part)
+    const Proj P, const double delta, double* __restrict__ ar_out, double* __restrict__ tile_part)
 {
     // Row-per-lane stores would touch 64 different lines per instruction; instead each wave stages its 64 rows
-    // in LDS (rows padded to 26 / 18 doubles: conflict-free ds_write_b128) and writes them back out as whole
+    // in LDS (rows padded to 18 doubles: conflict-free ds_write_b128) and writes them back out as whole
     // 1-KiB pieces, 16 contiguous bytes per lane.
-    constexpr int kJcPad = 26, kJprPad = 18;
+    constexpr int kArPad = 18;
     __shared__ double red[(kTileThreads / kWave) * kTileVals];
-    __shared__ __attribute__((aligned(16))) double stage[(kTileThreads / kWave) * kWave * kJcPad];
+    __shared__ __attribute__((aligned(16))) double stage[(kTileThreads / kWave) * kWave * kArPad];
     const Tile t = tiles[blockIdx.x];
     const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
     const bool fixed = cam_free[t.cam] < 0;
     PosePre pr;
     pose_load(campre + kPoseStride * (size_t)t.cam, pr);
-    double* wstage = stage + wave * kWave * kJcPad;
+    double* wstage = stage + wave * kWave * kArPad;
 
     double v[kTileVals];
 #pragma unroll
@@ -82,13 +81,13 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
         const bool act = o < t.count;
         const uint32_t wave_first = base + wave * kWave;                     // first observation of this wave's 64 rows
         const int n_rows = wave_first < t.count ? (int)min(t.count - wave_first, (uint32_t)kWave) : 0;
-        double r[4], jc[24], jp[12];
+        double r[4], jc[24], jp[12], am[12];
         if (act) {
             const size_t k = (size_t)t.start + o;
             const float4 m = uv[k];
             const uint32_t p = obs_pt[k];
             const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
-            v[27] += residual_jacobian(pr, x, m, P, delta, fixed, r, jc, jp);
+            v[27] += residual_jacobian(pr, x, m, P, delta, fixed, r, jc, jp, am);
             if (!fixed) {
                 int idx = 0;
 #pragma unroll
@@ -103,39 +102,22 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
         }
         if (n_rows > 0) {
             const size_t row0 = (size_t)t.start + wave_first;
-            // J_c: 64 rows x 24 doubles
+            // [A | r]: 64 rows x 16 doubles
             if (act) {
-                double2* w2 = reinterpret_cast<double2*>(wstage + lane * kJcPad);
+                double2* w2 = reinterpret_cast<double2*>(wstage + lane * kArPad);
 #pragma unroll
-                for (int i = 0; i < 12; i++) w2[i] = make_double2(jc[2 * i], jc[2 * i + 1]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            {
-                double2* g = reinterpret_cast<double2*>(jc_out + kJcRow * row0);
-#pragma unroll
-                for (int i = 0; i < 12; i++) {
-                    const int c = i * kWave + lane;           // 16-byte piece of the wave's 12-KiB block
-                    const int row = c / 12, col = (c % 12) * 2;
-                    if (row < n_rows) g[c] = *reinterpret_cast<const double2*>(wstage + row * kJcPad + col);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // [J_p | r]: 64 rows x 16 doubles
-            if (act) {
-                double2* w2 = reinterpret_cast<double2*>(wstage + lane * kJprPad);
-#pragma unroll
-                for (int i = 0; i < 6; i++) w2[i] = make_double2(jp[2 * i], jp[2 * i + 1]);
+                for (int i = 0; i < 6; i++) w2[i] = make_double2(am[2 * i], am[2 * i + 1]);
                 w2[6] = make_double2(r[0], r[1]);
                 w2[7] = make_double2(r[2], r[3]);
             }
             __builtin_amdgcn_wave_barrier();
             {
-                double2* g = reinterpret_cast<double2*>(jpr_out + kJprRow * row0);
+                double2* g = reinterpret_cast<double2*>(ar_out + kArRow * row0);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const int c = i * kWave + lane;
+                    const int c = i * kWave + lane;           // 16-byte piece of the wave's 8-KiB block
                     const int row = c / 8, col = (c % 8) * 2;
-                    if (row < n_rows) g[c] = *reinterpret_cast<const double2*>(wstage + row * kJprPad + col);
+                    if (row < n_rows) g[c] = *reinterpret_cast<const double2*>(wstage + row * kArPad + col);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -251,23 +233,30 @@ __global__ __launch_bounds__(64) void ba_cam_reduce_kernel(const uint32_t* __res
 // observation a 128-B row.
 __global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n_pt, const uint32_t* __restrict__ pt_start,
                                                                       const uint32_t* __restrict__ pt_obs,
-                                                                      const double* __restrict__ jpr,
+                                                                      const uint32_t* __restrict__ q_cam,
+                                                                      const double* __restrict__ ar,
+                                                                      const double* __restrict__ campre,
                                                                       double* __restrict__ C, double* __restrict__ gp)
 {
-    // kBacksubLanes lanes per point share its observations (a gather: more rows in flight), fixed butterfly at the end
+    // kBacksubLanes lanes per point share its observations (a gather: more rows in flight), fixed butterfly at the end.
+    // J_p = A R is rebuilt from the compact row and the camera's rotation (cached: 72 B per camera).
     const uint32_t p = (blockIdx.x * kPointBlock + threadIdx.x) / kBacksubLanes;
     const uint32_t sub = threadIdx.x % kBacksubLanes;
     const bool live = p < n_pt;
     double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2 = 0;
     if (live) {
         for (uint32_t q = pt_start[p] + sub; q < pt_start[p + 1]; q += kBacksubLanes) {
-            const double2* row = reinterpret_cast<const double2*>(jpr + kJprRow * (size_t)pt_obs[q]);
-            double w[16];
+            const double2* row = reinterpret_cast<const double2*>(ar + kArRow * (size_t)pt_obs[q]);
+            const double* Rc = campre + kPoseStride * (size_t)q_cam[q];
+            double w[16], R[9], jp[12];
 #pragma unroll
             for (int i = 0; i < 8; i++) { const double2 d = row[i]; w[2 * i] = d.x; w[2 * i + 1] = d.y; }
 #pragma unroll
+            for (int i = 0; i < 9; i++) R[i] = Rc[i];
+            compact_jp(w, R, jp);
+#pragma unroll
             for (int i = 0; i < 4; i++) {
-                const double a = w[i * 3], b = w[i * 3 + 1], c = w[i * 3 + 2], r = w[12 + i];
+                const double a = jp[i * 3], b = jp[i * 3 + 1], c = jp[i * 3 + 2], r = w[12 + i];
                 c0 += a * a; c1 += a * b; c2 += a * c; c3 += b * b; c4 += b * c; c5 += c * c;
                 g0 += a * r; g1 += b * r; g2 += c * r;
             }
@@ -299,22 +288,25 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_scale_kernel(uint32_t n_
 
 // ---------------------------------------------------------------------------------------------------
 // K5  ba_schur: one workgroup per chunk of consecutive points whose free cameras fit a window of KMAX local
-// slots.  The window's 6 KMAX x 6 KMAX matrix  sum_p Y_p W_p^T  (Y_p, W_p the point's 6 KMAX x 3 column blocks, zero
+// slots.  The window's 6 KMAX x 6 KMAX matrix  sum_p Y~_p W~_p^T  (Y~_p, W~_p the point's 6 KMAX x 3 column blocks, zero
 // rows for cameras that do not see it) is a GEMM over the concatenated point columns, and it runs on the f64 matrix
-// cores.  Per batch (<= 128 observations, <= PB points):
-//   * all lanes fetch the batch's Jacobian rows from HBM as 16-byte pieces - one batch AHEAD, into registers, so
-//     the gather latency hides behind the previous batch's products - and park them in LDS;
-//   * one lane per point inverts the damped 3x3 block in registers; three lanes per observation form W = J_c^T J_p
-//     and Y = W Cinv and write them into two zero-filled LDS images laid out [point column][window row];
+// cores.  W~ is J_c^T J_p without the per-camera factor T = blockdiag(M^T, I) (ba_device.h): ba_schur_reduce applies T
+// once per block.  Per batch (<= 128 observations, <= PB points):
+//   * all lanes fetch the A part (96 B) of the batch's compact rows from HBM as 16-byte pieces - requested a whole
+//     batch AHEAD, into registers - and park them in LDS;
+//   * one lane per point inverts the damped 3x3 block of the NEXT batch's points in registers; two lanes per
+//     observation form W~ and Y~ = W~ Cinv from A, the camera's rotation (an LDS table of the chunk's window cameras)
+//     and the point, and write them into two zero-filled LDS images laid out [point column][window row];
 //   * every wave owns a fixed set of 16x16 tiles of the window's upper triangle and accumulates
-//     v_mfma_f64_16x16x4_f64 products over the batch's columns in registers (no atomics, fixed order); the first
-//     6 KMAX lanes add the rhs part  Y g  with plain FMAs.
+//     v_mfma_f64_16x16x4_f64 products over the batch's columns in registers (no atomics, fixed order); lane groups
+//     add the rhs part  Y~ g  with plain FMAs.
 // The chunk's window goes to its own slab ([pair a <= b][6x6] then [camera][6]); ba_schur_reduce sums the slabs
 // per block in a fixed order, so the reduced camera system is bitwise reproducible.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kRawRow = 36;                       // J_c (24) + J_p (12) doubles staged per observation
+constexpr int kRawRow = 12;                       // A: 4x3 doubles staged per observation
 constexpr int kRawPieces = kRawRow / 2;           // 16-byte pieces per row
 constexpr int kSchurThreads = 512;
+constexpr int kCamTab = 10;                       // per window camera: R (9), first-order-branch flag
 
 typedef double schur_double4 __attribute__((ext_vector_type(4)));
 
@@ -327,7 +319,8 @@ struct SchurShape {
     static constexpr int NT1 = (ROWS + 15) / 16;           // 16-wide tiles per dimension
     static constexpr int NUP = NT1 * (NT1 + 1) / 2;        // tiles of the upper triangle
     static constexpr int TPW = (NUP + kSchurThreads / 64 - 1) / (kSchurThreads / 64);   // tiles per wave
-    static constexpr size_t lds_bytes = sizeof(double) * ((size_t)kBatchObs * kRawRow + 2 * (size_t)KB * LD + 2 * (PB * 6 + KB)) + 2 * kBatchObs;
+    static constexpr size_t lds_bytes =
+        sizeof(double) * ((size_t)kBatchObs * kRawRow + 2 * (size_t)KB * LD + 2 * (PB * 6 + KB + PB * 3) + KMAX * kCamTab) + 2 * kBatchObs;
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load
@@ -343,30 +336,40 @@ __device__ __forceinline__ void lds_barrier()
 template <int KMAX>
 __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
     const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches, const uint32_t* __restrict__ chunk_slab,
-    const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_pt, const uint8_t* __restrict__ q_slot, const double* __restrict__ jc,
-    const double* __restrict__ jpr, const double* __restrict__ C, const double* __restrict__ gp,
+    const uint32_t* __restrict__ chunk_cam, const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_pt,
+    const uint8_t* __restrict__ q_slot, const double* __restrict__ ar, const double* __restrict__ campre,
+    const double* __restrict__ pts, const double* __restrict__ C, const double* __restrict__ gp,
     const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv, double* __restrict__ slab,
     double* __restrict__ scal)
 {
     using Sh = SchurShape<KMAX>;
     constexpr int NT = kSchurThreads, PB = Sh::PB, LD = Sh::LD, KB = Sh::KB, NT1 = Sh::NT1, NUP = Sh::NUP, TPW = Sh::TPW;
-    constexpr int PPT = (kBatchObs * kRawPieces + NT - 1) / NT;   // raw pieces per lane
-    static_assert(NT >= 3 * kBatchObs, "W/Y staging uses three lanes per observation");
+    constexpr int NPIECE = kBatchObs * kRawPieces;                // 16-byte pieces per batch
+    constexpr int PPT = (NPIECE + NT - 1) / NT;                   // per lane
+    static_assert(NT >= 2 * kBatchObs, "W/Y staging uses two lanes per observation");
     static_assert(KB % 4 == 0 && (2 * KB * LD) % 2 == 0, "image shape");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* const raw = lds;                              // [kBatchObs][36]
-    double* const Yi = raw + kBatchObs * kRawRow;         // [KB][LD]   Yi[3 pl + c][6 slot + r] = Y[r][c]
+    double* const raw = lds;                              // [kBatchObs][12]
+    double* const Yi = raw + kBatchObs * kRawRow;         // [KB][LD]   Yi[3 pl + c][6 slot + r] = Y~[r][c]
     double* const Wi = Yi + KB * LD;                      // [KB][LD]
     double* const cil = Wi + KB * LD;                     // [2][PB][6] inverse of the damped point blocks, by batch parity
     double* const gl = cil + 2 * PB * 6;                  // [2][KB]    J_p^T r of the batch's points, index 3 pl + c
-    uint8_t* const pt_l = reinterpret_cast<uint8_t*>(gl + 2 * KB);   // batch-local point of each staged observation
-    uint8_t* const slot_l = pt_l + kBatchObs;                    // its window slot (255: fixed camera)
+    double* const xl = gl + 2 * KB;                       // [2][PB][3] the batch's points (linearisation point)
+    double* const camtab = xl + 2 * PB * 3;               // [KMAX][10] R and branch flag of the window's cameras
+    uint8_t* const pt_l = reinterpret_cast<uint8_t*>(camtab + KMAX * kCamTab);   // batch-local point of each staged observation
+    uint8_t* const slot_l = pt_l + kBatchObs;                                    // its window slot (255: fixed camera)
 
     const SchurChunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid % 64;
     const int wave = __builtin_amdgcn_readfirstlane(tid / 64);
     const int K = (int)ch.n_local, rows_used = 6 * K;
     const int ptl = tid - (NT - 64);   // point lane of the last wave (negative elsewhere)
+
+    // the window cameras' rotations, once per chunk (read by the W/Y lanes after the first barrier of the loop)
+    for (int e = tid; e < K * kCamTab; e += NT) {
+        const int slot = e / kCamTab, i = e - slot * kCamTab;
+        camtab[e] = campre[kPoseStride * (size_t)chunk_cam[(size_t)blockIdx.x * KMAX + slot] + (i < 9 ? i : 21)];
+    }
 
     // this wave's tiles of the upper triangle: u = wave, wave + 8, ..
     int t_i0[TPW], t_j0[TPW];
@@ -384,29 +387,26 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
     constexpr int kRhsGroups = KMAX <= 16 ? 4 : 2;   // kRhsGroups * 6 KMAX <= NT lanes share the rhs product
     double racc = 0.0;   // partial rhs of row tid % rows_used
 
-    // Prefetch registers, one batch ahead: this lane's 16-byte pieces of the batch's Jacobian rows (three passes of
-    // 512 lanes cover the 12 pieces of 128 J_c rows, two passes the 6 pieces of the [J_p | r] rows that hold J_p);
-    // its observation's point id and window slot; and - one lane per point - the point's J_p^T J_p, Jacobi scale
-    // and J_p^T r.  Everything that does not depend on the batch is worked out once, here; row offsets are 32-bit
-    // (the host refuses problems whose J_c array exceeds 4 GiB).
-    constexpr int kJcPieces = 12, kJpPieces = 6;
-    static_assert(PPT == 5 && 3 * NT == kBatchObs * kJcPieces && 2 * NT >= kBatchObs * kJpPieces, "piece passes");
+    // Prefetch registers, one batch ahead: this lane's 16-byte pieces of the A part of the batch's compact rows; its
+    // observation's point id and window slot; and - one lane per point - the point's J_p^T J_p, Jacobi scale, J_p^T r
+    // and position.  Everything that does not depend on the batch is worked out once, here; row offsets are 32-bit
+    // (the host refuses problems whose row array exceeds 4 GiB).
     double pre_x[PPT], pre_y[PPT];
     uint32_t pre_row[PPT];     // camera-major row of each piece's observation, fetched TWO batches ahead
     uint32_t pre_pt = 0;
     uint8_t pre_slot = 255;
-    double pre_c[6], pre_s[3], pre_g[3];
+    double pre_c[6], pre_s[3], pre_g[3], pre_p[3];
     uint32_t p_pack[PPT];      // pass s: batch-local observation of this lane's piece | piece inside the row << 8
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
-        const int piece = tid + (s < 3 ? s : s - 3) * NT, per = s < 3 ? kJcPieces : kJpPieces;
-        const int o = piece / per, part = piece - o * per;        // o >= 128 in the idle tail of the last pass
-        p_pack[s] = (uint32_t)o | ((uint32_t)part << 8);
+        const int piece = tid + s * NT;
+        const int o = piece / kRawPieces, part = piece - o * kRawPieces;   // o >= 128 in the idle tail of the last pass
+        p_pack[s] = (uint32_t)min(o, 255) | ((uint32_t)part << 8);
+        pre_x[s] = 0.0; pre_y[s] = 0.0; pre_row[s] = 0;
     }
     auto p_obs = [&](int s) __attribute__((always_inline)) { return (int)(p_pack[s] & 0xFFu); };
     auto p_part = [&](int s) __attribute__((always_inline)) { return p_pack[s] >> 8; };
-    const char* const jc_b = reinterpret_cast<const char*>(jc);
-    const char* const jp_b = reinterpret_cast<const char*>(jpr);
+    const char* const ar_b = reinterpret_cast<const char*>(ar);
     auto fetch_index = [&](uint32_t bi) __attribute__((always_inline)) {
         const SchurBatch bt = batches[bi];
         const int nq = (int)(bt.q_end - bt.q_begin);
@@ -419,8 +419,8 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
 #pragma unroll
         for (int s = 0; s < PPT; s++) {
             // unconditional: idle lanes carry row 0 from fetch_index and read a valid (cached) piece they never store
-            const uint32_t off = pre_row[s] * (uint32_t)((s < 3 ? kJcRow : kJprRow) * 8) + p_part(s) * 16u;
-            const double2 v = *reinterpret_cast<const double2*>((s < 3 ? jc_b : jp_b) + off);
+            const uint32_t off = pre_row[s] * (uint32_t)(kArRow * 8) + p_part(s) * 16u;
+            const double2 v = *reinterpret_cast<const double2*>(ar_b + off);
             pre_x[s] = v.x; pre_y[s] = v.y;
         }
         if (tid < nq) { pre_pt = q_pt[bt.q_begin + tid]; pre_slot = q_slot[bt.q_begin + tid]; }
@@ -429,18 +429,19 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
 #pragma unroll
             for (int i = 0; i < 6; i++) pre_c[i] = C[6 * p + i];
 #pragma unroll
-            for (int i = 0; i < 3; i++) { pre_s[i] = sp[3 * p + i]; pre_g[i] = gp[3 * p + i]; }
+            for (int i = 0; i < 3; i++) { pre_s[i] = sp[3 * p + i]; pre_g[i] = gp[3 * p + i]; pre_p[i] = pts[3 * p + i]; }
         }
     };
     // One lane per point of a batch (the last wave, which owns the fewest tiles): damped 3x3 block inverted in
-    // registers, for the batch AFTER the one being multiplied - a long dependent f64 chain on 16 lanes that would
-    // otherwise stall all eight waves at a barrier.  Results go to the parity buffer of that batch.
+    // registers, for the batch AFTER the one being multiplied - a long dependent f64 chain on a few lanes that would
+    // otherwise stall all eight waves at a barrier.  Results go to the parity buffers of that batch.
     auto point_phase = [&](uint32_t bi) __attribute__((always_inline)) {
         if (ptl < 0 || ptl >= PB) return;
         const SchurBatch bt = batches[bi];
         const int np = (int)(bt.p_end - bt.p_begin);
         double* cl = cil + (bi & 1) * (PB * 6);
         double* g = gl + (bi & 1) * KB;
+        double* xp = xl + (bi & 1) * (PB * 3);
         if (ptl < np) {
             double ci[6];
             const double m[6] = {pre_c[0] + point_lambda(pre_c[0], pre_s[0], lm), pre_c[1], pre_c[2],
@@ -449,7 +450,8 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
             double* o = Cinv + 6 * ((size_t)bt.p_begin + ptl);
 #pragma unroll
             for (int i = 0; i < 6; i++) { cl[ptl * 6 + i] = ci[i]; o[i] = ci[i]; }
-            g[ptl * 3] = pre_g[0]; g[ptl * 3 + 1] = pre_g[1]; g[ptl * 3 + 2] = pre_g[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { g[ptl * 3 + i] = pre_g[i]; xp[ptl * 3 + i] = pre_p[i]; }
         } else {
             g[ptl * 3] = 0.0; g[ptl * 3 + 1] = 0.0; g[ptl * 3 + 2] = 0.0;   // k padding of the rhs product
         }
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
         lds_barrier();   // previous batch's products are done with the LDS images
 #pragma unroll
         for (int s = 0; s < PPT; s++)
-            if (p_obs(s) < nq) reinterpret_cast<double2*>(raw)[p_obs(s) * kRawPieces + (s < 3 ? 0 : kJcPieces) + (int)p_part(s)] = make_double2(pre_x[s], pre_y[s]);
+            if (p_obs(s) < nq) reinterpret_cast<double2*>(raw)[p_obs(s) * kRawPieces + (int)p_part(s)] = make_double2(pre_x[s], pre_y[s]);
         const uint32_t my_pt = pre_pt;
         const uint8_t my_slot = pre_slot;
         // the prefetch registers are free again: request the next batch now, a whole batch time ahead of its use
@@ -481,28 +483,33 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
         if (tid < nq) { pt_l[tid] = (uint8_t)(my_pt - bt.p_begin); slot_l[tid] = my_slot; }
         const double* const cil_b = cil + (bi & 1) * (PB * 6);
         const double* const gl_b = gl + (bi & 1) * KB;
+        const double* const xl_b = xl + (bi & 1) * (PB * 3);
         lds_barrier();
-        // W = J_c^T J_p and Y = W Cinv: three lanes per observation, two of the six rows each
-        if (tid < 3 * nq) {
-            const int o = tid / 3, r0 = (tid % 3) * 2;
+        // W~ and Y~ = W~ Cinv: two lanes per observation, the rotation rows (0..2) and the translation rows (3..5)
+        if (tid < 2 * nq) {
+            const int o = tid >> 1, half = tid & 1;
             const int slot = slot_l[o];
             if (slot != 255) {
-                const double* row = raw + o * kRawRow;
-                const double* b = row + 24;
+                const double* A = raw + o * kRawRow;
                 const int pl = pt_l[o];
                 const double* ci = cil_b + pl * 6;
+                const double* ct = camtab + slot * kCamTab;
+                double Am[12], R[9], jp[12], v[3], w[18];
+#pragma unroll
+                for (int i = 0; i < 12; i++) Am[i] = A[i];
+#pragma unroll
+                for (int i = 0; i < 9; i++) R[i] = ct[i];
+                compact_v(R, ct[9] != 0.0, xl_b + pl * 3, v);
+                compact_jp(Am, R, jp);
+                compact_wt(Am, jp, v, w);
                 const double c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3], c4 = ci[4], c5 = ci[5];
-                const double b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5], b6 = b[6], b7 = b[7], b8 = b[8],
-                             b9 = b[9], b10 = b[10], b11 = b[11];
                 double* Wc = Wi + (pl * 3) * LD + slot * 6;
                 double* Yc = Yi + (pl * 3) * LD + slot * 6;
 #pragma unroll
-                for (int rr = 0; rr < 2; rr++) {
-                    const int r = r0 + rr;
-                    const double a0 = row[r], a1 = row[6 + r], a2 = row[12 + r], a3 = row[18 + r];
-                    const double w0 = a0 * b0 + a1 * b3 + a2 * b6 + a3 * b9;
-                    const double w1 = a0 * b1 + a1 * b4 + a2 * b7 + a3 * b10;
-                    const double w2 = a0 * b2 + a1 * b5 + a2 * b8 + a3 * b11;
+                for (int rr = 0; rr < 3; rr++) {
+                    const int r = half * 3 + rr;
+                    const double w0 = half ? w[(3 + rr) * 3] : w[rr * 3], w1 = half ? w[(3 + rr) * 3 + 1] : w[rr * 3 + 1],
+                                 w2 = half ? w[(3 + rr) * 3 + 2] : w[rr * 3 + 2];
                     Wc[r] = w0; Wc[LD + r] = w1; Wc[2 * LD + r] = w2;
                     Yc[r] = w0 * c0 + w1 * c1 + w2 * c2;
                     Yc[LD + r] = w0 * c1 + w1 * c3 + w2 * c4;
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
                     if (t_i0[j] >= 0) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j], acc[j], 0, 0, 0);   // wave-uniform
             }
         }
-        // rhs part Y g: lane group g = tid / rows_used takes the columns k = g (mod kRhsGroups); combined at the end
+        // rhs part Y~ g: lane group g = tid / rows_used takes the columns k = g (mod kRhsGroups); combined at the end
         if (tid < kRhsGroups * rows_used) {
             const int grp = tid / rows_used, rrow = tid - grp * rows_used;
             const double* y = Yi + rrow;
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
     }
 
     // the chunk's window: [pair a <= b][6x6] then [camera][6].  Accumulator register r of lane l holds element
-    // (i0 + 4 r + l/16, j0 + l%16); the same-camera blocks are symmetric (W Cinv W^T), so their lower entries are the
+    // (i0 + 4 r + l/16, j0 + l%16); the same-camera blocks are symmetric (W~ Cinv W~^T), so their lower entries are the
     // mirrored upper ones, wherever the 16x16 tiling cuts them.
     double* out = slab + chunk_slab[blockIdx.x];
     const int n_pair = K * (K + 1) / 2;
@@ -573,9 +580,9 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
         }
     }
     // rhs: the lane groups' partial sums are added in a fixed order through the (now idle) image memory
-    __syncthreads();
+    lds_barrier();
     if (tid < kRhsGroups * rows_used) Yi[tid] = racc;
-    __syncthreads();
+    lds_barrier();
     if (tid < rows_used) {
         double s = Yi[tid];
 #pragma unroll
@@ -591,8 +598,9 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
 // writes Y_a W_b^T to that pair's own slab slot.  No atomics; ba_schur_reduce adds the slots like any chunk's.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void ba_long_prepare_kernel(const LongPoint* __restrict__ long_pts, const uint32_t* __restrict__ lo_row,
-                                                             const uint32_t* __restrict__ lo_cam_off, const double* __restrict__ jc,
-                                                             const double* __restrict__ jpr, const double* __restrict__ C,
+                                                             const uint32_t* __restrict__ lo_cam, const uint32_t* __restrict__ lo_cam_off,
+                                                             const double* __restrict__ ar, const double* __restrict__ campre,
+                                                             const double* __restrict__ pts, const double* __restrict__ C,
                                                              const double* __restrict__ gp, const double* __restrict__ sp,
                                                              const LmDiag lm, double* __restrict__ Cinv, double* __restrict__ wy,
                                                              double* __restrict__ slab, double* __restrict__ scal)
@@ -612,21 +620,23 @@ __global__ __launch_bounds__(64) void ba_long_prepare_kernel(const LongPoint* __
         for (int i = 0; i < 6; i++) Cinv[6 * p + i] = ci[i];
     }
     const double g0 = gp[3 * p], g1 = gp[3 * p + 1], g2 = gp[3 * p + 2];
+    const double x[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
     for (uint32_t lo = lp.lo_begin + threadIdx.x; lo < lp.lo_end; lo += 64) {
-        const size_t q = lo_row[lo];
-        const double* a = jc + kJcRow * q;     // 4x6 row-major
-        const double* b = jpr + kJprRow * q;   // 4x3 row-major, then the residual
-        double bb[12];
+        const double* a = ar + kArRow * (size_t)lo_row[lo];
+        const double* pc = campre + kPoseStride * (size_t)lo_cam[lo];
+        double A[12], R[9], jp[12], v[3], w[18];
 #pragma unroll
-        for (int i = 0; i < 12; i++) bb[i] = b[i];
+        for (int i = 0; i < 12; i++) A[i] = a[i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = pc[i];
+        compact_v(R, pc[21] != 0.0, x, v);
+        compact_jp(A, R, jp);
+        compact_wt(A, jp, v, w);
         double* out = wy + 36 * (size_t)lo;
         double* cam = slab + lo_cam_off[lo];
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            const double a0 = a[r], a1 = a[6 + r], a2 = a[12 + r], a3 = a[18 + r];
-            const double w0 = a0 * bb[0] + a1 * bb[3] + a2 * bb[6] + a3 * bb[9];
-            const double w1 = a0 * bb[1] + a1 * bb[4] + a2 * bb[7] + a3 * bb[10];
-            const double w2 = a0 * bb[2] + a1 * bb[5] + a2 * bb[8] + a3 * bb[11];
+            const double w0 = w[r * 3], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
             const double y0 = w0 * ci[0] + w1 * ci[1] + w2 * ci[2];
             const double y1 = w0 * ci[1] + w1 * ci[3] + w2 * ci[4];
             const double y2 = w0 * ci[2] + w1 * ci[4] + w2 * ci[5];
@@ -649,34 +659,68 @@ __global__ __launch_bounds__(256) void ba_long_pairs_kernel(uint32_t n_pairs, co
     slab[pair_off[pair] + t] = Y[0] * W[0] + Y[1] * W[1] + Y[2] * W[2];
 }
 
-// S = B (diagonal blocks) - sum of the chunk windows, rhs = -g_c + sum of the chunk rhs parts, in the fixed
-// order of the host-built contribution lists; also exports diag(B) and g_c for the all-reduce.  Overwrites
-// S and rhs completely (no memset needed).
+// S = B (diagonal blocks) - T_a (sum of the chunk windows) T_b^T, rhs = -g_c + T_a (sum of the chunk rhs parts), in the
+// fixed order of the host-built contribution lists; T = blockdiag(M^T, I) is the per-camera factor the point kernels
+// leave out (ba_device.h).  Also exports diag(B) and g_c for the all-reduce.  Overwrites S and rhs completely.
 __global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, uint32_t n_free, const uint32_t* __restrict__ blk_ptr,
                                                              const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ cam_ptr,
                                                              const uint32_t* __restrict__ cam_off, const uint32_t* __restrict__ blk_row,
-                                                             const uint32_t* __restrict__ blk_col, const double* __restrict__ slab,
+                                                             const uint32_t* __restrict__ blk_col, const uint32_t* __restrict__ free_cam,
+                                                             const double* __restrict__ campre, const double* __restrict__ slab,
                                                              const double* __restrict__ B, const double* __restrict__ gc,
                                                              double* __restrict__ S, double* __restrict__ rhs,
                                                              double* __restrict__ diagB, double* __restrict__ gc_red)
 {
+    __shared__ double t0[36], t1[36];
     const uint32_t id = blockIdx.x;
     const int t = threadIdx.x;
     if (id < n_blocks) {
-        if (t >= 36) return;
-        double s = 0.0;
-        for (uint32_t e = blk_ptr[id]; e < blk_ptr[id + 1]; e++) s += slab[blk_off[e] + t];
-        const uint32_t f = blk_row[id];
-        S[36 * (size_t)id + t] = (f == blk_col[id] ? B[36 * (size_t)f + t] : 0.0) - s;
+        const uint32_t fa = blk_row[id], fb = blk_col[id];
+        const int r = t / 6, c = t % 6;
+        if (t < 36) {
+            double s = 0.0;
+            for (uint32_t e = blk_ptr[id]; e < blk_ptr[id + 1]; e++) s += slab[blk_off[e] + t];
+            t0[t] = s;
+        }
+        __syncthreads();
+        if (t < 36) {
+            // rows: U = T_a S~, U[r][c] = sum_i M_a[i][r] S~[i][c] for r < 3
+            const double* Ma = campre + kPoseStride * (size_t)free_cam[fa] + 9;
+            t1[t] = r < 3 ? Ma[r] * t0[c] + Ma[3 + r] * t0[6 + c] + Ma[6 + r] * t0[12 + c] : t0[t];
+        }
+        __syncthreads();
+        double v = 0.0;
+        if (t < 36) {
+            // columns: (U T_b^T)[r][c] = sum_j U[r][j] M_b[j][c] for c < 3
+            const double* Mb = campre + kPoseStride * (size_t)free_cam[fb] + 9;
+            v = c < 3 ? t1[r * 6] * Mb[c] + t1[r * 6 + 1] * Mb[3 + c] + t1[r * 6 + 2] * Mb[6 + c] : t1[t];
+        }
+        __syncthreads();
+        if (t < 36) t0[t] = v;
+        __syncthreads();
+        if (t < 36) {
+            // a same-camera block is symmetric only to rounding after the two products: its lower entries take the
+            // upper ones, so every consumer that mirrors or reads either triangle sees the same bits
+            const double w = (fa == fb && r > c) ? t0[c * 6 + r] : v;
+            S[36 * (size_t)id + t] = (fa == fb ? B[36 * (size_t)fa + t] : 0.0) - w;
+        }
     } else {
         const uint32_t f = id - n_blocks;
-        if (f >= n_free || t >= 6) return;
-        double s = 0.0;
-        for (uint32_t e = cam_ptr[f]; e < cam_ptr[f + 1]; e++) s += slab[cam_off[e] + t];
-        const double g = gc[6 * (size_t)f + t];
-        rhs[6 * (size_t)f + t] = s - g;
-        diagB[6 * (size_t)f + t] = B[36 * (size_t)f + t * 7];
-        gc_red[6 * (size_t)f + t] = g;
+        if (f >= n_free) return;
+        if (t < 6) {
+            double s = 0.0;
+            for (uint32_t e = cam_ptr[f]; e < cam_ptr[f + 1]; e++) s += slab[cam_off[e] + t];
+            t0[t] = s;
+        }
+        __syncthreads();
+        if (t < 6) {
+            const double* M = campre + kPoseStride * (size_t)free_cam[f] + 9;
+            const double v = t < 3 ? M[t] * t0[0] + M[3 + t] * t0[1] + M[6 + t] * t0[2] : t0[t];
+            const double g = gc[6 * (size_t)f + t];
+            rhs[6 * (size_t)f + t] = v - g;
+            diagB[6 * (size_t)f + t] = B[36 * (size_t)f + t * 7];
+            gc_red[6 * (size_t)f + t] = g;
+        }
     }
 }
 
@@ -706,8 +750,9 @@ __global__ __launch_bounds__(1024) void ba_cam_update_kernel(uint32_t n_cam, con
                                                             const double* __restrict__ dc_free,
                                                             const double* __restrict__ lc, const double* __restrict__ gc_red,
                                                             const double* __restrict__ lin_resid,
+                                                            const double* __restrict__ campre,
                                                             double* __restrict__ cams_out, double* __restrict__ dc_full,
-                                                            double* __restrict__ scal)
+                                                            double* __restrict__ dcw, double* __restrict__ scal)
 {
     __shared__ double red[16 * 5];
     double mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
@@ -732,6 +777,14 @@ __global__ __launch_bounds__(1024) void ba_cam_update_kernel(uint32_t n_cam, con
         cams_out[i] = xn;
         dc_full[i] = d;
     }
+    __syncthreads();   // this workgroup wrote all of dc_full
+    // what ba_backsub needs per camera: w = M dc_rot (the rotation part of J_c dc is A (w x v)) and dc_t
+    for (uint32_t i = threadIdx.x; i < n_cam * 6; i += 1024) {
+        const uint32_t c = i / 6, a = i % 6;
+        const double* dcc = dc_full + 6 * (size_t)c;
+        const double* M = campre + kPoseStride * (size_t)c + 9;
+        dcw[i] = a < 3 ? M[a * 3] * dcc[0] + M[a * 3 + 1] * dcc[1] + M[a * 3 + 2] * dcc[2] : dcc[a];
+    }
     mcc = wave_sum(mcc); st2 = wave_sum(st2); x2 = wave_sum(x2); gd = wave_sum(gd); gm = wave_max(gm);
     if (threadIdx.x % kWave == 0) {
         double* o = red + (threadIdx.x / kWave) * 5;
@@ -746,11 +799,13 @@ __global__ __launch_bounds__(1024) void ba_cam_update_kernel(uint32_t n_cam, con
 }
 
 // K8  back-substitution dp = -Cinv (g_p + sum_obs J_p^T (J_c dc)), candidate point with the box bounds,
-// per-workgroup partials {model-cost share, |step|^2, |x|^2, g.step, max|g|}
+// per-workgroup partials {model-cost share, |step|^2, |x|^2, g.step, max|g|}.
+// From the compact rows: J_c dc = A u with u = w x v + dc_t (w = M dc_rot per camera, from ba_cam_update; v = R x or x),
+// J_p^T (A u) = R^T (A^T (A u)).
 __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
     uint32_t n_pt, const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_obs,
-    const uint32_t* __restrict__ q_cam, const double* __restrict__ jc, const double* __restrict__ jpr,
-    const double* __restrict__ dc_full, const double* __restrict__ Cinv, const double* __restrict__ C,
+    const uint32_t* __restrict__ q_cam, const double* __restrict__ ar, const double* __restrict__ campre,
+    const double* __restrict__ dcw, const double* __restrict__ Cinv, const double* __restrict__ C,
     const double* __restrict__ gp, const double* __restrict__ sp, const double* __restrict__ pts, const LmDiag lm,
     const double bound_lo, const double bound_hi, double* __restrict__ pts_out, double* __restrict__ dp_out,
     double* __restrict__ part)
@@ -764,27 +819,33 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
     const bool live = p < n_pt;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
     if (live) {
-        // all 18 16-byte pieces of an observation's two rows are requested before the first multiply, and two
-        // observations are in flight per lane: this kernel is a gather of 320 B per observation
+        const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
 #pragma unroll 2
         for (uint32_t q = pt_start[p] + sub; q < pt_start[p + 1]; q += kBacksubLanes) {
             const size_t k = pt_obs[q];
-            const double* d = dc_full + 6 * (size_t)q_cam[q];
-            const double2* jcr = reinterpret_cast<const double2*>(jc + kJcRow * k);
-            const double2* jr = reinterpret_cast<const double2*>(jpr + kJprRow * k);
-            double2 a[12], b[6];
+            const size_t cam = q_cam[q];
+            const double2* row = reinterpret_cast<const double2*>(ar + kArRow * k);
+            const double* pc = campre + kPoseStride * cam;
+            const double* d = dcw + 6 * cam;
+            double A[12], R[9];
 #pragma unroll
-            for (int i = 0; i < 12; i++) a[i] = jcr[i];
+            for (int i = 0; i < 6; i++) { const double2 v2 = row[i]; A[2 * i] = v2.x; A[2 * i + 1] = v2.y; }
 #pragma unroll
-            for (int i = 0; i < 6; i++) b[i] = jr[i];
-            const double d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
-            const double jp[12] = {b[0].x, b[0].y, b[1].x, b[1].y, b[2].x, b[2].y, b[3].x, b[3].y, b[4].x, b[4].y, b[5].x, b[5].y};
+            for (int i = 0; i < 9; i++) R[i] = pc[i];
+            const bool small = pc[21] != 0.0;
+            const double w0 = d[0], w1 = d[1], w2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
+            double v[3];
+            compact_v(R, small, x, v);
+            const double u0 = w1 * v[2] - w2 * v[1] + d3, u1 = w2 * v[0] - w0 * v[2] + d4, u2 = w0 * v[1] - w1 * v[0] + d5;
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0;     // A^T (A u)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const double m = a[i * 3].x * d0 + a[i * 3].y * d1 + a[i * 3 + 1].x * d2 + a[i * 3 + 1].y * d3 + a[i * 3 + 2].x * d4 +
-                                 a[i * 3 + 2].y * d5;
-                t0 += jp[i * 3] * m; t1 += jp[i * 3 + 1] * m; t2 += jp[i * 3 + 2] * m;
+                const double m = A[i * 3] * u0 + A[i * 3 + 1] * u1 + A[i * 3 + 2] * u2;
+                z0 += A[i * 3] * m; z1 += A[i * 3 + 1] * m; z2 += A[i * 3 + 2] * m;
             }
+            t0 += R[0] * z0 + R[3] * z1 + R[6] * z2;
+            t1 += R[1] * z0 + R[4] * z1 + R[7] * z2;
+            t2 += R[2] * z0 + R[5] * z1 + R[8] * z2;
         }
     }
 #pragma unroll
@@ -839,11 +900,11 @@ void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, doub
 
 void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
                       const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
-                      double* jc, double* jpr, double* tile_part)
+                      double* ar, double* tile_part)
 {
     if (!n_tiles) return;
     hipLaunchKernelGGL(ba_linearize_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre, pts,
-                       cam_free, P, delta, jc, jpr, tile_part);
+                       cam_free, P, delta, ar, tile_part);
 }
 
 void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
@@ -870,12 +931,12 @@ void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_s
     hipLaunchKernelGGL(ba_cam_reduce_kernel, dim3(n_cam), dim3(64), 0, s, cam_tile_start, cam_free, tile_part, B, gc);
 }
 
-void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const double* jpr,
-                         double* C, double* gp)
+void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
+                         const double* ar, const double* campre, double* C, double* gp)
 {
     if (!n_pt) return;
-    hipLaunchKernelGGL(ba_point_reduce_kernel, dim3(backsub_blocks(n_pt)), dim3(kPointBlock), 0, s, n_pt,
-                       pt_start, pt_obs, jpr, C, gp);
+    hipLaunchKernelGGL(ba_point_reduce_kernel, dim3(backsub_blocks(n_pt)), dim3(kPointBlock), 0, s, n_pt, pt_start, pt_obs, q_cam, ar,
+                       campre, C, gp);
 }
 
 void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacobi, double* sp)
@@ -886,21 +947,21 @@ void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacob
 }
 
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
-                  const uint32_t* chunk_slab, const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* jc,
-                  const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* slab,
-                  double* scal)
+                  const uint32_t* chunk_slab, const uint32_t* chunk_cam, const uint32_t* pt_obs, const uint32_t* q_pt,
+                  const uint8_t* q_slot, const double* ar, const double* campre, const double* pts, const double* C, const double* gp,
+                  const double* sp, LmDiag lm, double* Cinv, double* slab, double* scal)
 {
     if (!n_chunks) return;
     if (kmax <= 16) {
         constexpr size_t lds = SchurShape<16>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ba_schur_kernel<16>), dim3(n_chunks), dim3(kSchurThreads), lds, s, chunks, batches, chunk_slab, pt_obs, q_pt,
-                           q_slot, jc, jpr, C, gp, sp, lm, Cinv, slab, scal);
+        hipLaunchKernelGGL((ba_schur_kernel<16>), dim3(n_chunks), dim3(kSchurThreads), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
+                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
     } else {
         constexpr size_t lds = SchurShape<32>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(kSchurThreads), lds, s, chunks, batches, chunk_slab, pt_obs, q_pt,
-                           q_slot, jc, jpr, C, gp, sp, lm, Cinv, slab, scal);
+        hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(kSchurThreads), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
+                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
     }
 }
 
@@ -911,26 +972,26 @@ __global__ void ba_status_poison_kernel(double* __restrict__ scal)
 
 void launch_status_poison(hipStream_t s, double* scal) { hipLaunchKernelGGL(ba_status_poison_kernel, dim3(1), dim3(1), 0, s, scal); }
 
-void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts, const uint32_t* lo_row, const uint32_t* lo_cam_off,
-                       uint32_t n_pairs, const uint32_t* pair_a, const uint32_t* pair_b, const uint32_t* pair_off, const double* jc,
-                       const double* jpr, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* wy,
-                       double* slab, double* scal)
+void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts, const uint32_t* lo_row, const uint32_t* lo_cam,
+                       const uint32_t* lo_cam_off, uint32_t n_pairs, const uint32_t* pair_a, const uint32_t* pair_b,
+                       const uint32_t* pair_off, const double* ar, const double* campre, const double* pts, const double* C,
+                       const double* gp, const double* sp, LmDiag lm, double* Cinv, double* wy, double* slab, double* scal)
 {
     if (!n_long) return;
-    hipLaunchKernelGGL(ba_long_prepare_kernel, dim3(n_long), dim3(64), 0, s, long_pts, lo_row, lo_cam_off, jc, jpr, C, gp, sp, lm, Cinv,
-                       wy, slab, scal);
+    hipLaunchKernelGGL(ba_long_prepare_kernel, dim3(n_long), dim3(64), 0, s, long_pts, lo_row, lo_cam, lo_cam_off, ar, campre, pts, C, gp,
+                       sp, lm, Cinv, wy, slab, scal);
     if (n_pairs)
         hipLaunchKernelGGL(ba_long_pairs_kernel, dim3((n_pairs + 6) / 7), dim3(256), 0, s, n_pairs, pair_a, pair_b, pair_off, wy, slab);
 }
 
 void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, const uint32_t* blk_ptr, const uint32_t* blk_off,
                          const uint32_t* cam_ptr, const uint32_t* cam_off, const uint32_t* blk_row, const uint32_t* blk_col,
-                         const double* slab, const double* B, const double* gc, double* S, double* rhs, double* diagB,
-                         double* gc_red)
+                         const uint32_t* free_cam, const double* campre, const double* slab, const double* B, const double* gc,
+                         double* S, double* rhs, double* diagB, double* gc_red)
 {
     if (!(n_blocks + n_free)) return;
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(n_blocks + n_free), dim3(64), 0, s, n_blocks, n_free, blk_ptr, blk_off, cam_ptr,
-                       cam_off, blk_row, blk_col, slab, B, gc, S, rhs, diagB, gc_red);
+                       cam_off, blk_row, blk_col, free_cam, campre, slab, B, gc, S, rhs, diagB, gc_red);
 }
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,
@@ -942,21 +1003,21 @@ void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double
 }
 
 void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams,
-                       const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid,
-                       double* cams_out, double* dc_full, double* scal)
+                       const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid, const double* campre,
+                       double* cams_out, double* dc_full, double* dcw, double* scal)
 {
-    hipLaunchKernelGGL(ba_cam_update_kernel, dim3(1), dim3(1024), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red, lin_resid,
-                       cams_out, dc_full, scal);
+    hipLaunchKernelGGL(ba_cam_update_kernel, dim3(1), dim3(1024), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red, lin_resid, campre,
+                       cams_out, dc_full, dcw, scal);
 }
 
 void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
-                    const double* jc, const double* jpr, const double* dc_full,
+                    const double* ar, const double* campre, const double* dcw,
                     const double* Cinv, const double* C, const double* gp, const double* sp, const double* pts,
                     LmDiag lm, double bound_lo, double bound_hi, double* pts_out, double* dp, double* part)
 {
     if (!n_pt) return;
     hipLaunchKernelGGL(ba_backsub_kernel, dim3(backsub_blocks(n_pt)), dim3(kPointBlock), 0, s, n_pt, pt_start,
-                       pt_obs, q_cam, jc, jpr, dc_full, Cinv, C, gp, sp, pts, lm, bound_lo, bound_hi, pts_out, dp, part);
+                       pt_obs, q_cam, ar, campre, dcw, Cinv, C, gp, sp, pts, lm, bound_lo, bound_hi, pts_out, dp, part);
 }
 
 }  // namespace soslam

@@ -85,15 +85,17 @@ struct soslam_ba {
     DevBuf<SchurBatch> batches;
     // long-track points (beyond the Schur window / batch limits)
     DevBuf<LongPoint> long_pts;
-    DevBuf<uint32_t> lo_row, lo_cam_off, pair_a, pair_b, pair_off;
+    DevBuf<uint32_t> lo_row, lo_cam, lo_cam_off, pair_a, pair_b, pair_off;
+    DevBuf<uint32_t> chunk_cam, free_cam;   // camera of each Schur window slot / of each free index
     DevBuf<double> long_wy;
     uint32_t n_long = 0, n_long_pairs = 0, n_short = 0;
+    std::vector<uint32_t> h_obs_cam, h_obs_pt;   // camera / internal point of each internal observation (debug read-back)
     DevBuf<uint32_t> row_ptr, ent_col, ent_blk, blk_row, blk_col;
 
     // state and work buffers
     DevBuf<double> cams[2], pts[2];
     int cur = 0;
-    DevBuf<double> campre, jc, jpr, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
+    DevBuf<double> campre, campre_c, ar, dcw, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
     DevBuf<double> lin_resid, lin_work, dense, band, bandT, band_dinv, cr_ws;
     DevBuf<double> reduce_own;          // library-owned reduce buffer
     double* reduce = nullptr;           // [S blocks | rhs | diagB | gc_red | tail(4)] [scalars(SC_COUNT)]
@@ -208,8 +210,9 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     // free-camera numbering
     h->h_cam_free.assign(n_cam, -1);
     uint32_t nf = 0;
+    std::vector<uint32_t> free_cam;   // camera of each free index
     for (uint32_t c = 0; c < n_cam; c++)
-        if (!(fixed && fixed[c])) h->h_cam_free[c] = (int32_t)nf++;
+        if (!(fixed && fixed[c])) { h->h_cam_free[c] = (int32_t)nf++; free_cam.push_back(c); }
     h->n_free = nf;
 
     SETUP_MARK("begin");
@@ -276,6 +279,8 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         cam_start[ocam[k] + 1]++;
     }
     for (uint32_t c = 0; c < n_cam; c++) cam_start[c + 1] += cam_start[c];
+    h->h_obs_cam = v_obs_cam;
+    h->h_obs_pt = v_obs_pt;
 
     SETUP_MARK("obs order");
     // tiles: <= kTileObs observations of one camera each
@@ -400,6 +405,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     std::vector<SchurChunk> chunks;
     std::vector<SchurBatch> batches;
     std::vector<uint32_t> chunk_slab;                       // offset of each chunk's window in the slab
+    std::vector<uint32_t> chunk_cam;                        // [chunk][K] camera of each window slot
     std::vector<std::vector<uint32_t>> blk_contrib(h->n_blocks), cam_contrib(nf);
     uint64_t slab_count = 0;
     std::vector<uint8_t> q_slot(n_obs, 255);
@@ -433,6 +439,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             const uint32_t base = (uint32_t)slab_count;
             chunk_slab.push_back(base);
             const int KL = (int)local.size();
+            for (int a = 0; a < K; a++) chunk_cam.push_back(a < KL ? free_cam[local[a]] : 0u);   // camera of each window slot
             int pair = 0;
             for (int a = 0; a < KL; a++)
                 for (int b = a; b < KL; b++, pair++) {
@@ -463,7 +470,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     }
     // long-track points: one slab slot per camera pair and per camera, through the same contribution lists
     std::vector<LongPoint> long_pts;
-    std::vector<uint32_t> lo_row, lo_cam_off, pair_a, pair_b, pair_off;
+    std::vector<uint32_t> lo_row, lo_cam, lo_cam_off, pair_a, pair_b, pair_off;
     {
         std::vector<uint32_t> lf;   // free camera of each long observation of the current point
         for (uint32_t p = n_short; p < n_pt; p++) {
@@ -478,6 +485,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                 }
                 lf.push_back((uint32_t)f);
                 lo_row.push_back(pt_obs[q]);
+                lo_cam.push_back(v_obs_cam[pt_obs[q]]);
             }
             lp.lo_end = (uint32_t)lo_row.size();
             const size_t k = lf.size();
@@ -549,8 +557,11 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->chunks.upload(chunks, s));
     SOSLAM_CHECK(h->batches.upload(batches, s));
     SOSLAM_CHECK(h->chunk_slab.upload(chunk_slab, s));
+    SOSLAM_CHECK(h->chunk_cam.upload(chunk_cam, s));
+    SOSLAM_CHECK(h->free_cam.upload(free_cam, s));
     SOSLAM_CHECK(h->long_pts.upload(long_pts, s));
     SOSLAM_CHECK(h->lo_row.upload(lo_row, s));
+    SOSLAM_CHECK(h->lo_cam.upload(lo_cam, s));
     SOSLAM_CHECK(h->lo_cam_off.upload(lo_cam_off, s));
     SOSLAM_CHECK(h->pair_a.upload(pair_a, s));
     SOSLAM_CHECK(h->pair_b.upload(pair_b, s));
@@ -576,8 +587,13 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         SOSLAM_CHECK(h->pts[i].alloc((size_t)n_pt * 3));
     }
     SOSLAM_CHECK(h->campre.alloc((size_t)n_cam * kPoseStride));
-    SOSLAM_CHECK(h->jc.alloc((size_t)n_obs * kJcRow));
-    SOSLAM_CHECK(h->jpr.alloc((size_t)n_obs * kJprRow));
+    if ((uint64_t)n_obs * kArRow * 8 > 0xFFFFFFF0ull) {
+        set_last_error("%u observations: the compact Jacobian array exceeds the 32-bit row offsets of ba_schur", n_obs);
+        return SOSLAM_ERR_INVALID_ARGUMENT;
+    }
+    SOSLAM_CHECK(h->campre_c.alloc((size_t)n_cam * kPoseStride));
+    SOSLAM_CHECK(h->ar.alloc((size_t)n_obs * kArRow));
+    SOSLAM_CHECK(h->dcw.alloc((size_t)n_cam * 6));
     SOSLAM_CHECK(h->tile_part.alloc((size_t)h->n_tiles * kTileVals));
     SOSLAM_CHECK(h->cost_part.alloc(h->n_tiles));
     SOSLAM_CHECK(h->C.alloc((size_t)n_pt * 6));
@@ -643,13 +659,13 @@ int linearize(soslam_ba* h)
         StageScope sc(h, SOSLAM_STAGE_LINEARIZE);
         launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);
         launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p,
-                         h->proj, h->opt.huber_delta, h->jc.p, h->jpr.p, h->tile_part.p);
+                         h->proj, h->opt.huber_delta, h->ar.p, h->tile_part.p);
         launch_cam_reduce(s, h->n_cam, h->cam_tile_start.p, h->cam_free.p, h->tile_part.p, h->B.p, h->gc.p);
         launch_sum_strided(s, h->tile_part.p, h->n_tiles, kTileVals, 27, 0.5, h->scalp() + SC_COST_X);
     }
     {
         StageScope sc(h, SOSLAM_STAGE_POINT_REDUCE);
-        launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->jpr.p, h->C.p, h->gp.p);
+        launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->C.p, h->gp.p);
         if (!h->scale_init) launch_point_scale(s, h->n_pt, h->C.p, h->opt.jacobi_scaling, h->sp.p);
     }
     SOSLAM_HIP_CHECK(hipGetLastError());
@@ -676,10 +692,11 @@ BsrView bsr_view(const soslam_ba* h)
 void run_schur(soslam_ba* h, const LmDiag& lm)
 {
     hipStream_t s = h->stream;
-    launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->pt_obs.p, h->q_pt.p, h->q_slot.p,
-                 h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
-    launch_schur_long(s, h->n_long, h->long_pts.p, h->lo_row.p, h->lo_cam_off.p, h->n_long_pairs, h->pair_a.p, h->pair_b.p,
-                      h->pair_off.p, h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->long_wy.p, h->slab.p, h->scalp());
+    launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pt_obs.p, h->q_pt.p,
+                 h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
+    launch_schur_long(s, h->n_long, h->long_pts.p, h->lo_row.p, h->lo_cam.p, h->lo_cam_off.p, h->n_long_pairs, h->pair_a.p, h->pair_b.p,
+                      h->pair_off.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->long_wy.p,
+                      h->slab.p, h->scalp());
 }
 
 constexpr uint32_t kPcgMultiMinRows = 64;   // below this one workgroup does a whole PCG iteration faster than three launches
@@ -693,8 +710,8 @@ int take_step(soslam_ba* h, double radius)
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
         run_schur(h, lm);
         launch_schur_reduce(s, h->n_blocks, h->n_free, h->blk_contrib_ptr.p, h->blk_contrib_off.p, h->cam_contrib_ptr.p,
-                            h->cam_contrib_off.p, h->blk_row.p, h->blk_col.p, h->slab.p, h->B.p, h->gc.p, h->S(), h->rhs(),
-                            h->diagB(), h->gc_red());
+                            h->cam_contrib_off.p, h->blk_row.p, h->blk_col.p, h->free_cam.p, h->campre.p, h->slab.p, h->B.p, h->gc.p,
+                            h->S(), h->rhs(), h->diagB(), h->gc_red());
         SOSLAM_HIP_CHECK(hipMemcpyAsync(h->tail(), h->scalp() + SC_COST_X, sizeof(double), hipMemcpyDeviceToDevice, s));
     }
     {
@@ -750,20 +767,21 @@ int take_step(soslam_ba* h, double radius)
                 resid = h->lin_resid.p;
             }
         }
-        launch_cam_update(s, h->n_cam, h->cam_free.p, h->cams[h->cur].p, h->dc_free.p, h->lc.p, h->gc_red(), resid,
-                          h->cams[h->cur ^ 1].p, h->dc_full.p, h->scalp());
+        launch_cam_update(s, h->n_cam, h->cam_free.p, h->cams[h->cur].p, h->dc_free.p, h->lc.p, h->gc_red(), resid, h->campre.p,
+                          h->cams[h->cur ^ 1].p, h->dc_full.p, h->dcw.p, h->scalp());
     }
     {
         StageScope sc(h, SOSLAM_STAGE_BACKSUB);
-        launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->jc.p, h->jpr.p, h->dc_full.p, h->Cinv.p, h->C.p,
+        launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->dcw.p, h->Cinv.p, h->C.p,
                        h->gp.p, h->sp.p, h->pts[h->cur].p, lm, h->opt.lower_bound, h->opt.upper_bound, h->pts[h->cur ^ 1].p,
                        h->dp.p, h->part.p);
         launch_sum5(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS);
     }
     {
         StageScope sc(h, SOSLAM_STAGE_COST);
-        launch_pose_prepare(s, h->n_cam, h->cams[h->cur ^ 1].p, h->campre.p);
-        launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur ^ 1].p, h->proj,
+        // the candidate gets its own pose table: campre stays at the linearisation point, the compact rows need it
+        launch_pose_prepare(s, h->n_cam, h->cams[h->cur ^ 1].p, h->campre_c.p);
+        launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->proj,
                     h->opt.huber_delta, h->cost_part.p);
         launch_sum_strided(s, h->cost_part.p, h->n_tiles, 1, 0, 0.5, h->scalp() + SC_CAND_COST);
     }
@@ -1181,7 +1199,6 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
     SOSLAM_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     if (!h->linearized) SOSLAM_CHECK(linearize(h));
-    launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);   // the last cost evaluation left the candidate's block there
     if (kernel == SOSLAM_KERNEL_SCHUR || kernel == SOSLAM_KERNEL_BACKSUB) {
         // these read the point scales; make sure they exist
         if (!h->scale_init) launch_point_scale(s, h->n_pt, h->C.p, h->opt.jacobi_scaling, h->sp.p);
@@ -1194,21 +1211,22 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
         switch (kernel) {
         case SOSLAM_KERNEL_LINEARIZE:
             launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p,
-                             h->proj, h->opt.huber_delta, h->jc.p, h->jpr.p, h->tile_part.p);
+                             h->proj, h->opt.huber_delta, h->ar.p, h->tile_part.p);
             break;
         case SOSLAM_KERNEL_COST:
             launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->proj,
                         h->opt.huber_delta, h->cost_part.p);
             break;
         case SOSLAM_KERNEL_POINT_REDUCE:
-            launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->jpr.p, h->C.p, h->gp.p);
+            launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->C.p, h->gp.p);
             break;
         case SOSLAM_KERNEL_SCHUR:
-            launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->pt_obs.p, h->q_pt.p, h->q_slot.p,
-                         h->jc.p, h->jpr.p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
+            launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pt_obs.p, h->q_pt.p,
+                         h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p,
+                         h->scalp());
             break;
         case SOSLAM_KERNEL_BACKSUB:
-            launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->jc.p, h->jpr.p, h->dc_full.p, h->Cinv.p,
+            launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->dcw.p, h->Cinv.p,
                            h->C.p, h->gp.p, h->sp.p, h->pts[h->cur].p, lm, h->opt.lower_bound, h->opt.upper_bound,
                            h->pts[h->cur ^ 1].p, h->dp.p, h->part.p);
             break;
@@ -1217,7 +1235,7 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
     };
     if (kernel < 0 || kernel > SOSLAM_KERNEL_BACKSUB) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return SOSLAM_ERR_INVALID_ARGUMENT; }
     if (kernel == SOSLAM_KERNEL_BACKSUB) {
-        SOSLAM_HIP_CHECK(hipMemsetAsync(h->dc_full.p, 0, sizeof(double) * 6 * h->n_cam, s));
+        SOSLAM_HIP_CHECK(hipMemsetAsync(h->dcw.p, 0, sizeof(double) * 6 * h->n_cam, s));
         run_schur(h, lm);
     }
     once();  // warm-up
@@ -1262,21 +1280,43 @@ int soslam_ba_debug_read(soslam_ba* h, int32_t what, void* dst, uint64_t bytes)
     const size_t n_obs = h->n_obs;
     switch (what) {
     case SOSLAM_DBG_RESIDUALS:
-    case SOSLAM_DBG_JAC_POINT: {
-        const size_t w = what == SOSLAM_DBG_RESIDUALS ? 4 : 12, off = what == SOSLAM_DBG_RESIDUALS ? 12 : 0;
-        SOSLAM_CHECK(need(n_obs * w * sizeof(double)));
-        std::vector<double> tmp(n_obs * kJprRow);
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->jpr.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
-        for (size_t i = 0; i < n_obs; i++) std::memcpy(out + w * h->obs_int2user[i], &tmp[i * kJprRow + off], w * sizeof(double));
-        return SOSLAM_OK;
-    }
+    case SOSLAM_DBG_JAC_POINT:
     case SOSLAM_DBG_JAC_CAM: {
-        SOSLAM_CHECK(need(n_obs * 24 * sizeof(double)));
-        std::vector<double> tmp(n_obs * kJcRow);
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->jc.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        // the device keeps compact rows [A | r]; J_p = A R and J_c = [A D | A], D = -[v]x M, are rebuilt here exactly as the
+        // kernels rebuild them (ba_device.h), from the pose table and the points of the linearisation point
+        const size_t w = what == SOSLAM_DBG_RESIDUALS ? 4 : (what == SOSLAM_DBG_JAC_POINT ? 12 : 24);
+        SOSLAM_CHECK(need(n_obs * w * sizeof(double)));
+        std::vector<double> rows(n_obs * kArRow), pre((size_t)h->n_cam * kPoseStride), pts((size_t)h->n_pt * 3);
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(rows.data(), h->ar.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(pre.data(), h->campre.p, pre.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(pts.data(), h->pts[h->cur].p, pts.size() * sizeof(double), hipMemcpyDeviceToHost, s));
         SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
-        for (size_t i = 0; i < n_obs; i++) std::memcpy(out + 24 * (size_t)h->obs_int2user[i], &tmp[i * kJcRow], 24 * sizeof(double));
+        for (size_t i = 0; i < n_obs; i++) {
+            const double* A = &rows[i * kArRow];
+            double* o = out + w * h->obs_int2user[i];
+            if (what == SOSLAM_DBG_RESIDUALS) { std::memcpy(o, A + 12, 4 * sizeof(double)); continue; }
+            const uint32_t cam = h->h_obs_cam[i];
+            const double* R = &pre[(size_t)cam * kPoseStride];
+            const double* M = R + 9;
+            if (what == SOSLAM_DBG_JAC_POINT) {
+                for (int k = 0; k < 4; k++)
+                    for (int j = 0; j < 3; j++) o[k * 3 + j] = A[k * 3] * R[j] + A[k * 3 + 1] * R[3 + j] + A[k * 3 + 2] * R[6 + j];
+                continue;
+            }
+            if (h->h_cam_free[cam] < 0) { std::memset(o, 0, 24 * sizeof(double)); continue; }
+            const double* x = &pts[3 * (size_t)h->h_obs_pt[i]];
+            double v[3], D[9];
+            for (int k = 0; k < 3; k++) v[k] = R[21] != 0.0 ? x[k] : R[k * 3] * x[0] + R[k * 3 + 1] * x[1] + R[k * 3 + 2] * x[2];
+            for (int j = 0; j < 3; j++) {
+                D[0 * 3 + j] = -(v[1] * M[2 * 3 + j] - v[2] * M[1 * 3 + j]);
+                D[1 * 3 + j] = -(v[2] * M[0 * 3 + j] - v[0] * M[2 * 3 + j]);
+                D[2 * 3 + j] = -(v[0] * M[1 * 3 + j] - v[1] * M[0 * 3 + j]);
+            }
+            for (int k = 0; k < 4; k++) {
+                for (int j = 0; j < 3; j++) o[k * 6 + j] = A[k * 3] * D[j] + A[k * 3 + 1] * D[3 + j] + A[k * 3 + 2] * D[6 + j];
+                o[k * 6 + 3] = A[k * 3]; o[k * 6 + 4] = A[k * 3 + 1]; o[k * 6 + 5] = A[k * 3 + 2];
+            }
+        }
         return SOSLAM_OK;
     }
     case SOSLAM_DBG_COST:
