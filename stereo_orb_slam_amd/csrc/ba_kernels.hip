@@ -248,11 +248,11 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n
         for (uint32_t q = pt_start[p] + sub; q < pt_start[p + 1]; q += kBacksubLanes) {
             const double2* row = reinterpret_cast<const double2*>(ar + kArRow * (size_t)pt_obs[q]);
             const double* Rc = campre + kPoseStride * (size_t)q_cam[q];
-            double w[16], R[9], jp[12];
+            double w[16], R[10], jp[12];
 #pragma unroll
             for (int i = 0; i < 8; i++) { const double2 d = row[i]; w[2 * i] = d.x; w[2 * i + 1] = d.y; }
 #pragma unroll
-            for (int i = 0; i < 9; i++) R[i] = Rc[i];
+            for (int i = 0; i < 5; i++) { const double2 d = reinterpret_cast<const double2*>(Rc)[i]; R[2 * i] = d.x; R[2 * i + 1] = d.y; }
             compact_jp(w, R, jp);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -827,11 +827,11 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
             const double2* row = reinterpret_cast<const double2*>(ar + kArRow * k);
             const double* pc = campre + kPoseStride * cam;
             const double* d = dcw + 6 * cam;
-            double A[12], R[9];
+            double A[12], R[10];
 #pragma unroll
             for (int i = 0; i < 6; i++) { const double2 v2 = row[i]; A[2 * i] = v2.x; A[2 * i + 1] = v2.y; }
 #pragma unroll
-            for (int i = 0; i < 9; i++) R[i] = pc[i];
+            for (int i = 0; i < 5; i++) { const double2 v2 = reinterpret_cast<const double2*>(pc)[i]; R[2 * i] = v2.x; R[2 * i + 1] = v2.y; }
             const bool small = pc[21] != 0.0;
             const double w0 = d[0], w1 = d[1], w2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
             double v[3];
