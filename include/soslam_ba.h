@@ -217,7 +217,7 @@ void soslam_ba_shard_range(uint32_t n_pt, int32_t rank, int32_t world, uint32_t*
 /* ---- stage-level access: parity tests, roofline measurement ------------------------------------------ */
 
 enum {
-    SOSLAM_KERNEL_LINEARIZE = 0,     /* ba_linearize: r, J_c, J_p written (368 B / observation) */
+    SOSLAM_KERNEL_LINEARIZE = 0,     /* ba_linearize: reads 48 B, writes the compact row [A | r] = 128 B per observation */
     SOSLAM_KERNEL_COST = 1,          /* ba_cost: residual + loss only (48 B / observation) */
     SOSLAM_KERNEL_POINT_REDUCE = 2,
     SOSLAM_KERNEL_SCHUR = 3,
@@ -229,7 +229,7 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
 
 enum {
     SOSLAM_DBG_RESIDUALS = 0,   /* n_obs*4  f64, caller's observation order, loss-corrected */
-    SOSLAM_DBG_JAC_CAM = 1,     /* n_obs*24 f64, 4x6 row-major, zero for fixed cameras */
+    SOSLAM_DBG_JAC_CAM = 1,     /* n_obs*24 f64, 4x6 row-major, zero for fixed cameras (rebuilt from the compact rows) */
     SOSLAM_DBG_JAC_POINT = 2,   /* n_obs*12 f64, 4x3 row-major */
     SOSLAM_DBG_COST = 3,        /* 1 f64: cost at the current state */
     SOSLAM_DBG_S_DENSE = 4,     /* (6F)^2 f64 row-major, both triangles, damping included (last step) */
