@@ -3,12 +3,13 @@
 // Data layout in HBM:
 //   uv      [n_obs] float4          camera-major observation order (bucketed by camera)
 //   obs_pt  [n_obs] u32             internal point id (points sorted by first camera)
-//   jc      [n_obs][24] f64         loss-corrected 4x6 pose Jacobian, 192-B rows, camera-major like uv
-//   jpr     [n_obs][16] f64         loss-corrected 4x3 point Jacobian + 4 residuals, 128-B rows, camera-major
-//                                   (point-major passes gather whole rows through the pt_obs index)
+//   ar      [n_obs][16] f64         compact Jacobian row [A (4x3) | r (4)], 128-B rows, camera-major like uv; J_p = A R and
+//                                   J_c = [A D | A] are rebuilt by the consumers (ba_device.h); point-major passes
+//                                   gather whole rows through the pt_obs index
 //   C/gp    [n_pt][6] / [n_pt][3]   per-point J_p^T J_p (xx xy xz yy yz zz) and J_p^T r
 //   S       [n_blocks][36]          upper block-sparse reduced camera matrix (6x6 row-major blocks)
-// Every kernel is HBM-bound streaming / gather work at ~2 flop/B; nothing here is GEMM-shaped.
+// The kernels are HBM-bound streaming / gather work at a few flop/B; the one GEMM-shaped piece, the Schur window
+// product, runs on the f64 matrix cores.
 #include "ba_kernels.h"
 
 namespace soslam {
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_scale_kernel(uint32_t n_
 // slots.  The window's 6 KMAX x 6 KMAX matrix  sum_p Y~_p W~_p^T  (Y~_p, W~_p the point's 6 KMAX x 3 column blocks, zero
 // rows for cameras that do not see it) is a GEMM over the concatenated point columns, and it runs on the f64 matrix
 // cores.  W~ is J_c^T J_p without the per-camera factor T = blockdiag(M^T, I) (ba_device.h): ba_schur_reduce applies T
-// once per block.  Per batch (<= 128 observations, <= PB points):
+// once per block.  Per batch (<= 256 observations, <= PB points):
 //   * all lanes fetch the A part (96 B) of the batch's compact rows from HBM as 16-byte pieces - requested a whole
 //     batch AHEAD, into registers - and park them in LDS;
 //   * one lane per point inverts the damped 3x3 block of the NEXT batch's points in registers; two lanes per
@@ -396,16 +397,16 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
     uint32_t pre_pt = 0;
     uint8_t pre_slot = 255;
     double pre_c[6], pre_s[3], pre_g[3], pre_p[3];
-    uint32_t p_pack[PPT];      // pass s: batch-local observation of this lane's piece | piece inside the row << 8
+    uint32_t p_pack[PPT];      // pass s: batch-local observation of this lane's piece | piece inside the row << 16
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
         const int piece = tid + s * NT;
-        const int o = piece / kRawPieces, part = piece - o * kRawPieces;   // o >= 128 in the idle tail of the last pass
-        p_pack[s] = (uint32_t)min(o, 255) | ((uint32_t)part << 8);
+        const int o = piece / kRawPieces, part = piece - o * kRawPieces;   // o >= kBatchObs in the idle tail of the last pass
+        p_pack[s] = (uint32_t)o | ((uint32_t)part << 16);
         pre_x[s] = 0.0; pre_y[s] = 0.0; pre_row[s] = 0;
     }
-    auto p_obs = [&](int s) __attribute__((always_inline)) { return (int)(p_pack[s] & 0xFFu); };
-    auto p_part = [&](int s) __attribute__((always_inline)) { return p_pack[s] >> 8; };
+    auto p_obs = [&](int s) __attribute__((always_inline)) { return (int)(p_pack[s] & 0xFFFFu); };
+    auto p_part = [&](int s) __attribute__((always_inline)) { return p_pack[s] >> 16; };
     const char* const ar_b = reinterpret_cast<const char*>(ar);
     auto fetch_index = [&](uint32_t bi) __attribute__((always_inline)) {
         const SchurBatch bt = batches[bi];
