@@ -777,14 +777,18 @@ __global__ __launch_bounds__(1024) void ba_cam_update_kernel(uint32_t n_cam, con
         st2 += e * e;
         cams_out[i] = xn;
         dc_full[i] = d;
-    }
-    __syncthreads();   // this workgroup wrote all of dc_full
-    // what ba_backsub needs per camera: w = M dc_rot (the rotation part of J_c dc is A (w x v)) and dc_t
-    for (uint32_t i = threadIdx.x; i < n_cam * 6; i += 1024) {
-        const uint32_t c = i / 6, a = i % 6;
-        const double* dcc = dc_full + 6 * (size_t)c;
-        const double* M = campre + kPoseStride * (size_t)c + 9;
-        dcw[i] = a < 3 ? M[a * 3] * dcc[0] + M[a * 3 + 1] * dcc[1] + M[a * 3 + 2] * dcc[2] : dcc[a];
+        // what ba_backsub needs per camera: w = M dc_rot (the rotation part of J_c dc is A (w x v)) and dc_t; read from
+        // the solver's output directly, so no lane depends on another lane's store
+        double wv = d;
+        if (a < 3) {
+            wv = 0.0;
+            if (f >= 0) {
+                const double* M = campre + kPoseStride * (size_t)c + 9 + a * 3;
+                const double* dr = dc_free + 6 * (size_t)f;
+                wv = M[0] * dr[0] + M[1] * dr[1] + M[2] * dr[2];
+            }
+        }
+        dcw[i] = wv;
     }
     mcc = wave_sum(mcc); st2 = wave_sum(st2); x2 = wave_sum(x2); gd = wave_sum(gd); gm = wave_max(gm);
     if (threadIdx.x % kWave == 0) {

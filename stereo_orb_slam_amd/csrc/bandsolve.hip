@@ -405,8 +405,9 @@ __global__ __launch_bounds__(64) void band_solve_kernel(const uint32_t n, const 
         rz = wave_sum(rz);
         rz = __shfl(rz, 0, kWave);
         const double rz_old = state[PS_RZ];
-        const double beta = state[PS_ROUNDS] == 0.0 ? 0.0 : rz / rz_old;
-        for (uint32_t i = lane; i < n * 6; i += kWave) p[i] = x[i] + beta * p[i];
+        const bool first = state[PS_ROUNDS] == 0.0;   // p is uninitialised memory then: do not multiply it by zero
+        const double beta = first ? 0.0 : rz / rz_old;
+        for (uint32_t i = lane; i < n * 6; i += kWave) p[i] = first ? x[i] : x[i] + beta * p[i];
         __syncthreads();
         if (lane == 0) state[PS_RZ] = rz;
     }
@@ -440,7 +441,9 @@ __global__ __launch_bounds__(1024) void pcg_direction_kernel(uint32_t n, const d
     for (uint32_t i = threadIdx.x; i < n; i += 1024) rz += r[i] * z[i];
     rz = block_sum(rz, red);
     const double beta = state[PS_ROUNDS] == 0.0 ? 0.0 : rz / state[PS_RZ];
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) p[i] = z[i] + beta * p[i];
+    // first round: p is uninitialised memory, and 0 * garbage is not 0 when the garbage is a NaN
+    const bool first = state[PS_ROUNDS] == 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) p[i] = first ? z[i] : z[i] + beta * p[i];
     __syncthreads();
     if (threadIdx.x == 0) state[PS_RZ] = rz;
 }

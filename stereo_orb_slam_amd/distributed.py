@@ -47,10 +47,12 @@ class TorchAllReduce:
             lib_stream = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
             with torch.cuda.stream(lib_stream):
                 if self.host_staged:
-                    # gloo stages device tensors through host memory on streams of its own; seen on this image: its
-                    # copy back can still be in flight when the call returns.  Rehearsal backend only - be blunt.
+                    # rehearsal backends without a device path of their own (gloo): stage through the host here,
+                    # synchronously - wait for the library's kernels, reduce a host copy, copy back, wait again
                     lib_stream.synchronize()
-                    dist.all_reduce(view, op=rop, group=self.group)
+                    host = view.cpu()
+                    dist.all_reduce(host, op=rop, group=self.group)
+                    view.copy_(host)
                     torch.cuda.synchronize(dev)
                 else:
                     dist.all_reduce(view, op=rop, group=self.group)
@@ -65,6 +67,10 @@ def attach(handle, rank: int, world: int, device, group=None) -> TorchAllReduce:
     """Give a loaded BundleAdjustment handle a torch-owned reduce buffer and the all-reduce callback."""
     n = handle.reduce_buffer_count()
     t = torch.zeros(n, dtype=torch.float64, device=device)
+    if t.is_cuda:
+        # torch fills the tensor asynchronously on ITS current stream; the library writes into it from its own stream.
+        # Without this wait the fill can land after the first linearisation has put its cost there.
+        torch.cuda.current_stream(t.device).synchronize()
     handle.set_reduce_buffer(t.data_ptr(), n)
     cb = TorchAllReduce(t, group)
     import torch.distributed as dist

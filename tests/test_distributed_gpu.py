@@ -39,7 +39,9 @@ def _worker(rank, world, port, out_dir):
         log = h.iteration_log()
         cams, _ = h.get_state()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cost=np.array([it.cost for it in log]),
-             accepted=np.array([it.accepted for it in log]), cams=cams)
+             accepted=np.array([it.accepted for it in log]), cams=cams,
+             detail=np.array([[it.cost, it.candidate_cost, it.model_cost_change, it.relative_decrease, it.radius, it.step_norm,
+                               it.accepted, it.valid, it.linear_iterations] for it in log]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,6 +65,9 @@ def test_two_ranks_follow_the_single_rank_trajectory(tmp_path):
         out.mkdir()
         mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
         r0, r1 = np.load(out / "rank0.npz"), np.load(out / "rank1.npz")
+        if not np.array_equal(r0["detail"], r1["detail"]):
+            np.set_printoptions(precision=12, linewidth=220)
+            print("rank 0 log [cost cand mcc rho radius step acc valid lin]:\n", r0["detail"], "\nrank 1 log:\n", r1["detail"])
         assert np.array_equal(r0["cost"], r1["cost"]) and np.array_equal(r0["cams"], r1["cams"])   # replicas agree bitwise
         assert r0["accepted"].all()
         np.testing.assert_allclose(r0["cost"], ref_cost, rtol=1e-9)
