@@ -6,8 +6,10 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "soslam_ba.h"
@@ -57,6 +59,14 @@ struct DevBuf {
         size_t want = count + count / 4;   // head room: consecutive windows differ by a few percent
         if (want == 0) want = 1;
         SOSLAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)));
+        // SOSLAM_POISON_ALLOC=1 (development): fresh floating-point allocations are filled with 0xFF bytes (NaN), so that
+        // any read of memory the library did not write shows up in the tests instead of depending on what the allocator
+        // happened to hand out.  Index buffers are zeroed: a poisoned index would fault the GPU instead of failing a test.
+        static const bool poison = std::getenv("SOSLAM_POISON_ALLOC") != nullptr;
+        if (poison) {
+            SOSLAM_HIP_CHECK(hipMemset(p, std::is_floating_point<T>::value ? 0xFF : 0x00, want * sizeof(T)));
+            SOSLAM_HIP_CHECK(hipDeviceSynchronize());   // the fill runs on the null stream; the handles' streams do not wait for it
+        }
         n = count;
         cap = want;
         return SOSLAM_OK;
