@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace soslam {
@@ -20,7 +22,7 @@ namespace {
 
 constexpr int kRowsPerWg = 42;   // block rows per workgroup
 constexpr int kThreads = 256;
-enum { ST_BB = 0, ST_ITERS = 1, ST_BREAKDOWN = 2, ST_COUNT = 4 };
+enum { ST_BB = 0, ST_ITERS = 1, ST_BREAKDOWN = 2, ST_DONE = 3, ST_COUNT = 4 };
 
 struct PcgBufs {
     double *p, *z, *q, *minv, *part_pq, *part_rz, *part_rr, *state;   // part_rz / part_rr: [2][n_wg]
@@ -159,8 +161,12 @@ __device__ __forceinline__ double coop_sum(const double* __restrict__ part, uint
     return block_sum256(v, red);
 }
 
+// The residual partials are double-buffered by iteration parity, so once the solve has converged the OTHER parity slot
+// still holds an unconverged sum: convergence has to be remembered (ST_DONE, set by the direction kernel of the
+// iteration that reached it), or every second launch of the rest of the chunk would iterate on stale data.
 __device__ __forceinline__ bool converged(const PcgBufs& w, int parity, double tol, double* red)
 {
+    if (w.state[ST_DONE] != 0.0) return true;   // uniform: written by an earlier launch
     const double rr = coop_sum(w.part_rr + parity * w.n_wg, w.n_wg, red);
     const double bb = w.state[ST_BB];
     return !(rr > tol * tol * bb) || w.state[ST_BREAKDOWN] != 0.0;
@@ -232,6 +238,10 @@ __global__ __launch_bounds__(kThreads) void pcgm_direction_kernel(const uint32_t
     // the update kernel ran iff the system had not converged at `parity`; it may have converged now - p is then unused
     __shared__ double red[4];
     if (converged(w, parity, tol, red)) return;
+    if (converged(w, parity ^ 1, tol, red)) {   // this iteration's update reached the tolerance: remember it
+        if (blockIdx.x == 0 && threadIdx.x == 0) w.state[ST_DONE] = 1.0;
+        return;
+    }
     const double rz_old = coop_sum(w.part_rz + parity * w.n_wg, w.n_wg, red);
     const double rz_new = coop_sum(w.part_rz + (parity ^ 1) * w.n_wg, w.n_wg, red);
     const double beta = rz_new / rz_old;

@@ -129,3 +129,25 @@ def test_one_call_and_errors(gpu):
                                  L.ptr(np.ascontiguousarray(g.meas)), L.ptr(np.ascontiguousarray(g.info)), C.byref(s))
     assert st == L.ERR_INVALID_ARGUMENT
     np.testing.assert_array_equal(est2, g.est)
+
+
+def test_degenerate_graphs(gpu):
+    """What PoseGraphOptimizer::Optimize can hand over at the start of a run: a single fixed vertex without edges, and
+    two vertices joined by one odometry edge (the free one must move onto the measurement, chi2 -> 0)."""
+    pg, synth, L = gpu
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    info = np.diag([0.01, 0.01, 0.01, 1.0, 1.0, 1.0]).reshape(36)
+    with pg.PoseGraph() as h:
+        h.set_graph(ident[None, :].copy(), np.array([1], np.uint8), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros((0, 7)), info)
+        s = h.optimize()
+        assert s.initial_chi2 == 0.0 and s.final_chi2 == 0.0
+        np.testing.assert_array_equal(h.estimates(), ident[None, :])
+    est = np.stack([ident, np.array([0.3, -0.1, 0.2, 0, 0, 0, 1.0])])
+    meas = np.array([[1.0, 0.0, 0.0, 0.0, 0.0, np.sin(0.05), np.cos(0.05)]])
+    with pg.PoseGraph() as h:
+        h.set_graph(est.copy(), np.array([1, 0], np.uint8), np.array([0], np.uint32), np.array([1], np.uint32), meas, info)
+        s = h.optimize()
+        out = h.estimates()
+    assert s.final_chi2 < 1e-12 * max(1.0, s.initial_chi2) + 1e-14
+    np.testing.assert_array_equal(out[0], ident)
+    np.testing.assert_allclose(out[1], meas[0], atol=1e-7)
