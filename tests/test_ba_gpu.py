@@ -568,3 +568,18 @@ def test_config3_first_iterations_match_the_oracle(gpu, oracle_lib):
     for a, b in zip(glog, olog):
         assert a.cost == pytest.approx(b.cost, rel=REL_COST) and a.accepted == b.accepted
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+
+
+@pytest.mark.parametrize("solver", [0, 1, 2, 3])
+@pytest.mark.parametrize("n_cam", [2, 3, 5])
+def test_tiny_windows_every_solver(gpu, oracle_lib, n_cam, solver):
+    """Two to five frames (one to four free cameras): the start of a run.  Every solver setting must land on the
+    oracle's solution - these sizes take the degenerate paths (band of width 0 or 1, a single block row)."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, n_cam=n_cam, n_pt=200, track_mode=0, track_len=n_cam, spacing=0.4)
+    try:
+        cams, pts, summ = ba.optimize(p, ba.default_options(max_iterations=10, linear_solver=solver, pcg_tolerance=1e-12))
+    except L.SoslamError:
+        assert solver == 3 and False, "band Cholesky must accept a chain of this size"
+    ocams, opts_, osum, _ = _oracle_solve(oracle_lib, p, max_iterations=10)
+    _compare_solutions(summ, cams, pts, osum, ocams, opts_)
