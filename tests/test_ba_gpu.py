@@ -583,3 +583,17 @@ def test_tiny_windows_every_solver(gpu, oracle_lib, n_cam, solver):
         assert solver == 3 and False, "band Cholesky must accept a chain of this size"
     ocams, opts_, osum, _ = _oracle_solve(oracle_lib, p, max_iterations=10)
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+
+
+
+def test_active_point_bounds(gpu, oracle_lib, prob1):
+    """The reference bounds every point coordinate (bundle_adjuster.cpp:104-108; +-1e4 there, never active).  Here the box
+    is +-25 and the start is clipped into it, so most depths sit ON the bound and want to leave: candidates are projected
+    onto the box, exactly as in the oracle, and the solution honours it."""
+    ba, synth, L = gpu
+    q = synth.BaProblem(prob1.poses_wc, np.clip(prob1.points, -25.0, 25.0), prob1.obs_cam, prob1.obs_pt, prob1.obs_uv, prob1.proj_l, prob1.proj_r)
+    o = ba.default_options(max_iterations=12, lower_bound=-25.0, upper_bound=25.0)
+    cams, pts, summ = ba.optimize(q, o)
+    ocams, opts_, osum, _ = _oracle_solve(oracle_lib, q, max_iterations=12, lower_bound=-25.0, upper_bound=25.0)
+    assert pts.max() <= 25.0 and pts.min() >= -25.0 and (pts == 25.0).sum() > 100
+    _compare_solutions(summ, cams, pts, osum, ocams, opts_)
