@@ -13,6 +13,6 @@ p = synth.generate_ba(cfg)
 h = ba.BundleAdjustment(ba.default_options(linear_solver=3))
 h.load(p)
 tag = os.environ.get("SOSLAM_LIN_VARIANT", "")
-for k, name, bpo in ((0, "ba_linearize", 176), (1, "ba_cost", 48), (2, "ba_point_reduce", 132), (3, "ba_schur", 104), (4, "ba_backsub", 104)):
+for k, name, bpo in ((0, "ba_linearize", 128), (1, "ba_cost", 48), (2, "ba_point_reduce", 88), (3, "ba_schur", 56), (4, "ba_backsub", 56)):
     ms = h.time_kernel(k, reps)
     print(f"{tag} {name:16s} {ms * 1e3:9.1f} us  {bpo * p.n_obs / ms / 1e6:8.1f} GB/s")

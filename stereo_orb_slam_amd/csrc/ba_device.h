@@ -198,45 +198,78 @@ __device__ __forceinline__ double residual_jacobian(const PosePre& pr, const dou
     return rho0;
 }
 
-// ---- compact Jacobian rows -----------------------------------------------------------------------------
-// ba_linearize stores per observation only A (4x3: the loss-corrected derivative of the four image coordinates with
-// respect to the camera-frame point) and the corrected residual r: 16 doubles.  With the camera's R, M and the point x
+// What ba_linearize needs per observation, without forming J_c or J_p: the corrected residual r, A (4x3: the
+// loss-corrected derivative of the image coordinates with respect to the camera-frame point) and D = d(R x)/dw (3x3).
+// Same arithmetic as residual_jacobian up to that point.  Returns rho(|r|^2).
+__device__ __forceinline__ double residual_ad(const PosePre& pr, const double* x, const float4 uv, const Proj& P, double delta,
+                                              double* __restrict__ r, double* __restrict__ Am, double* __restrict__ D)
+{
+    double yr[3], y[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        yr[i] = pr.R[i * 3] * x[0] + pr.R[i * 3 + 1] * x[1] + pr.R[i * 3 + 2] * x[2];
+        y[i] = yr[i] + pr.t[i];
+    }
+    double A[12], ul, vl, ur, vr;
+    project_rows(P.l, y, ul, vl, A);
+    project_rows(P.r, y, ur, vr, A + 6);
+    r[0] = ul - (double)uv.x; r[1] = vl - (double)uv.y; r[2] = ur - (double)uv.z; r[3] = vr - (double)uv.w;
+    double rho0, rho1;
+    huber(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], delta, rho0, rho1);
+    const double sw = sqrt(rho1);
+    {
+        const double v0 = pr.small ? x[0] : yr[0], v1 = pr.small ? x[1] : yr[1], v2 = pr.small ? x[2] : yr[2];
+        const double* M = pr.M;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            D[0 * 3 + j] = -(v1 * M[2 * 3 + j] - v2 * M[1 * 3 + j]);
+            D[1 * 3 + j] = -(v2 * M[0 * 3 + j] - v0 * M[2 * 3 + j]);
+            D[2 * 3 + j] = -(v0 * M[1 * 3 + j] - v1 * M[0 * 3 + j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) Am[i] = A[i] * sw;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] *= sw;
+    return rho0;
+}
+
+// ---- compact rows --------------------------------------------------------------------------------------
+// With A (4x3) the loss-corrected derivative of the four image coordinates with respect to the camera-frame point and
+// r the corrected residual,
 //     J_p = A R                              (4x3)
-//     J_c = [ A D | A ],  D = -[v]x M        (4x6; v = R x, or x on the first-order branch)
-// so every consumer rebuilds what it needs from 128 B per observation instead of reading 320 B.  The kernels that
-// reduce per point go one step further and keep M out of the per-observation work: with
-//     W~ = [ [v]x (A^T A R) ; A^T A R ] (6x3)      one has    J_c^T J_p = T W~,   T = blockdiag(M^T, I)
-//     (D^T = (-[v]x M)^T = M^T [v]x)
-// and T is applied once per camera block after the sums (ba_schur_reduce), or folded into the step (ba_cam_update
-// hands ba_backsub  w = M dc_rot  per camera:  J_c dc = A (w x v + dc_t)).
+//     J_c = [ A D | A ],  D = -[v]x M        (4x6; v = R x, or x on the first-order branch; M = R Jr per camera)
+// and everything downstream of ba_linearize needs A only through  G = A^T A  (3x3 symmetric) and  h = A^T r:
+//     J_p^T J_p = R^T G R        J_p^T r = R^T h        J_p^T (J_c dc) = R^T G (w x v + dc_t),  w = M dc_rot
+//     J_c^T J_p = T W~,   W~ = [ [v]x (G R) ; G R ],   T = blockdiag(M^T, I)      (D^T = M^T [v]x)
+// ba_linearize therefore stores per observation the row [Gxx Gxy Gxz Gyy Gyz Gzz | hx hy hz | 0]: 80 B instead of the
+// 320 B of r, J_c and J_p.  T is applied once per camera block after the per-point sums (ba_schur_reduce), w comes
+// from ba_cam_update.
 __device__ __forceinline__ void compact_v(const double* __restrict__ R, bool small, const double* __restrict__ x, double* __restrict__ v)
 {
 #pragma unroll
     for (int i = 0; i < 3; i++) v[i] = small ? x[i] : R[i * 3] * x[0] + R[i * 3 + 1] * x[1] + R[i * 3 + 2] * x[2];
 }
 
-// J_p = A R  (row-major 4x3)
-__device__ __forceinline__ void compact_jp(const double* __restrict__ A, const double* __restrict__ R, double* __restrict__ jp)
+// Z = G R (3x3 row-major), G symmetric as xx xy xz yy yz zz
+__device__ __forceinline__ void compact_gr(const double* __restrict__ G, const double* __restrict__ R, double* __restrict__ z)
 {
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) jp[i * 3 + j] = A[i * 3] * R[j] + A[i * 3 + 1] * R[3 + j] + A[i * 3 + 2] * R[6 + j];
-}
-
-// W~ (6x3 row-major): rows 3..5 = A^T J_p, rows 0..2 = [v]x (A^T J_p) = v x column
-__device__ __forceinline__ void compact_wt(const double* __restrict__ A, const double* __restrict__ jp, const double* __restrict__ v,
-                                           double* __restrict__ w)
-{
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-            w[(3 + r) * 3 + c] = A[r] * jp[c] + A[3 + r] * jp[3 + c] + A[6 + r] * jp[6 + c] + A[9 + r] * jp[9 + c];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const double z0 = w[9 + c], z1 = w[12 + c], z2 = w[15 + c];     // column c of A^T J_p
-        // [v]x z = v x z
+        z[0 + c] = G[0] * R[c] + G[1] * R[3 + c] + G[2] * R[6 + c];
+        z[3 + c] = G[1] * R[c] + G[3] * R[3 + c] + G[4] * R[6 + c];
+        z[6 + c] = G[2] * R[c] + G[4] * R[3 + c] + G[5] * R[6 + c];
+    }
+}
+
+// W~ (6x3 row-major): rows 3..5 = G R, rows 0..2 = [v]x (G R) = v x column
+__device__ __forceinline__ void compact_wt(const double* __restrict__ G, const double* __restrict__ R, const double* __restrict__ v,
+                                           double* __restrict__ w)
+{
+    compact_gr(G, R, w + 9);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double z0 = w[9 + c], z1 = w[12 + c], z2 = w[15 + c];
         w[0 + c] = v[1] * z2 - v[2] * z1;
         w[3 + c] = v[2] * z0 - v[0] * z2;
         w[6 + c] = v[0] * z1 - v[1] * z0;

@@ -13,7 +13,7 @@ namespace soslam {
 constexpr int kTileObs = 1024;       // observations per linearize/cost workgroup (one camera per tile)
 constexpr int kTileThreads = 256;    // lanes per tile: up to 4 observations each
 constexpr int kTileVals = 28;        // 21 (J_c^T J_c upper) + 6 (J_c^T r) + 1 (rho)
-constexpr int kArRow = 16;            // f64 per observation in the compact Jacobian array [A (4x3 row-major) | r (4)], 128 B
+constexpr int kArRow = 10;            // f64 per observation in the compact row array [G (xx xy xz yy yz zz) | h (3) | 0], 80 B
 constexpr int kBatchObs = 256;       // observations staged per Schur batch (also the most one windowed point may have)
 // points per Schur batch: the batch's point columns (3 each) are the k dimension of the window GEMM, and two
 // [3 PB][6 KMAX + 1] f64 images must fit LDS next to the staged rows
@@ -69,6 +69,11 @@ void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, doub
 void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
                       const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
                       double* ar, double* tile_part);
+
+// parity tests: residual (n_obs*4), J_c (n_obs*24), J_p (n_obs*12) of every observation, internal observation order
+void launch_debug_rows(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
+                       const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
+                       double* r_out, double* jc_out, double* jp_out);
 
 void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
                  const double* campre, const double* pts, const Proj& P, double delta, double* cost_part);

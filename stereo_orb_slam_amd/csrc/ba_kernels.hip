@@ -51,8 +51,8 @@ __global__ __launch_bounds__(64) void ba_pose_prepare_kernel(uint32_t n_cam, con
 // camera's rotation block is workgroup-uniform and arrives through scalar loads.  Each lane evaluates up
 // to 4 observations (strided by 256, coalesced), writes their corrected Jacobian rows, and keeps its share
 // of J_c^T J_c / J_c^T r / rho in registers; one wave-shuffle + LDS reduction per workgroup.
-// Only the compact row [A | r] (ba_device.h) leaves the kernel: 16 (uv) + 4 (point id) + 24 (point) in, 128 out
-// = 172 B per observation ("fused" in the sense of SURVEY.md section 8(d): J_c and J_p are never written).
+// Only the compact row [G | h] (ba_device.h) leaves the kernel: 16 (uv) + 4 (point id) + 24 (point) in, 80 out
+// = 124 B per observation ("fused" in the sense of SURVEY.md section 8(d): J_c and J_p are never written).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
     const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
     // Row-per-lane stores would touch 64 different lines per instruction; instead each wave stages its 64 rows
     // in LDS (rows padded to 18 doubles: conflict-free ds_write_b128) and writes them back out as whole
     // 1-KiB pieces, 16 contiguous bytes per lane.
-    constexpr int kArPad = 18;
+    constexpr int kArPad = 10;   // 80-B rows: 16-byte aligned, and stride 20 dwords keeps the ds_write_b128 conflict-free enough
     __shared__ double red[(kTileThreads / kWave) * kTileVals];
     __shared__ __attribute__((aligned(16))) double stage[(kTileThreads / kWave) * kWave * kArPad];
     const Tile t = tiles[blockIdx.x];
@@ -77,48 +77,87 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
 #pragma unroll
     for (int i = 0; i < kTileVals; i++) v[i] = 0.0;
 
-    for (uint32_t base = 0; base < t.count; base += kTileThreads) {
+    // The lane's (up to four) observations are a chain of dependent gathers (index -> point) in front of a long
+    // arithmetic block: all measurements and indices are requested up front, and each point one observation ahead.
+    constexpr int kObsPerLane = kTileObs / kTileThreads;
+    float4 m_all[kObsPerLane];
+    uint32_t p_all[kObsPerLane];
+#pragma unroll
+    for (int j = 0; j < kObsPerLane; j++) {
+        const uint32_t o = (uint32_t)j * kTileThreads + tid;
+        const size_t k = (size_t)t.start + (o < t.count ? o : 0);
+        m_all[j] = uv[k];
+        p_all[j] = obs_pt[k];
+    }
+    double xn[3] = {pts[3 * (size_t)p_all[0]], pts[3 * (size_t)p_all[0] + 1], pts[3 * (size_t)p_all[0] + 2]};
+
+#pragma unroll
+    for (int j = 0; j < kObsPerLane; j++) {
+        const uint32_t base = (uint32_t)j * kTileThreads;
+        if (base >= t.count) break;   // uniform
         const uint32_t o = base + tid;
         const bool act = o < t.count;
         const uint32_t wave_first = base + wave * kWave;                     // first observation of this wave's 64 rows
         const int n_rows = wave_first < t.count ? (int)min(t.count - wave_first, (uint32_t)kWave) : 0;
-        double r[4], jc[24], jp[12], am[12];
+        double r[4], am[12], G[6] = {0, 0, 0, 0, 0, 0}, hh[3] = {0, 0, 0};
+        const double x[3] = {xn[0], xn[1], xn[2]};
+        if (j + 1 < kObsPerLane) {
+            const size_t pn = p_all[j + 1 < kObsPerLane ? j + 1 : j];
+            xn[0] = pts[3 * pn]; xn[1] = pts[3 * pn + 1]; xn[2] = pts[3 * pn + 2];
+        }
         if (act) {
-            const size_t k = (size_t)t.start + o;
-            const float4 m = uv[k];
-            const uint32_t p = obs_pt[k];
-            const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
-            v[27] += residual_jacobian(pr, x, m, P, delta, fixed, r, jc, jp, am);
+            double D[9];
+            v[27] += residual_ad(pr, x, m_all[j], P, delta, r, am, D);
+            // G = A^T A, h = A^T r: the compact row, and all the camera sums need
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double a0 = am[i * 3], a1 = am[i * 3 + 1], a2 = am[i * 3 + 2];
+                G[0] += a0 * a0; G[1] += a0 * a1; G[2] += a0 * a2; G[3] += a1 * a1; G[4] += a1 * a2; G[5] += a2 * a2;
+                hh[0] += a0 * r[i]; hh[1] += a1 * r[i]; hh[2] += a2 * r[i];
+            }
             if (!fixed) {
+                // J_c = A [D | I]:  J_c^T J_c = [ D^T G D, D^T G ; G D, G ],  J_c^T r = [ D^T h ; h ]
+                const double Gf[9] = {G[0], G[1], G[2], G[1], G[3], G[4], G[2], G[4], G[5]};
+                double K[9];   // D^T G
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) K[a * 3 + b] = D[a] * Gf[b] + D[3 + a] * Gf[3 + b] + D[6 + a] * Gf[6 + b];
+                // upper triangle in the order (0,0) (0,1) .. (0,5) (1,1) .. (5,5)
                 int idx = 0;
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
-                    for (int b = a; b < 6; b++)
-                        v[idx++] += jc[a] * jc[b] + jc[6 + a] * jc[6 + b] + jc[12 + a] * jc[12 + b] + jc[18 + a] * jc[18 + b];
+                    for (int b = a; b < 6; b++) {
+                        double val;
+                        if (a < 3 && b < 3) val = K[a * 3] * D[b] + K[a * 3 + 1] * D[3 + b] + K[a * 3 + 2] * D[6 + b];
+                        else if (a < 3) val = K[a * 3 + (b - 3)];
+                        else val = Gf[(a - 3) * 3 + (b - 3)];
+                        v[idx++] += val;
+                    }
 #pragma unroll
-                for (int a = 0; a < 6; a++)
-                    v[21 + a] += jc[a] * r[0] + jc[6 + a] * r[1] + jc[12 + a] * r[2] + jc[18 + a] * r[3];
+                for (int a = 0; a < 3; a++) {
+                    v[21 + a] += D[a] * hh[0] + D[3 + a] * hh[1] + D[6 + a] * hh[2];
+                    v[24 + a] += hh[a];
+                }
             }
         }
         if (n_rows > 0) {
             const size_t row0 = (size_t)t.start + wave_first;
-            // [A | r]: 64 rows x 16 doubles
+            // [G | h | 0] with G = A^T A, h = A^T r: 64 rows x 10 doubles
             if (act) {
                 double2* w2 = reinterpret_cast<double2*>(wstage + lane * kArPad);
-#pragma unroll
-                for (int i = 0; i < 6; i++) w2[i] = make_double2(am[2 * i], am[2 * i + 1]);
-                w2[6] = make_double2(r[0], r[1]);
-                w2[7] = make_double2(r[2], r[3]);
+                w2[0] = make_double2(G[0], G[1]); w2[1] = make_double2(G[2], G[3]); w2[2] = make_double2(G[4], G[5]);
+                w2[3] = make_double2(hh[0], hh[1]); w2[4] = make_double2(hh[2], 0.0);
             }
             __builtin_amdgcn_wave_barrier();
             {
                 double2* g = reinterpret_cast<double2*>(ar_out + kArRow * row0);
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int c = i * kWave + lane;           // 16-byte piece of the wave's 8-KiB block
-                    const int row = c / 8, col = (c % 8) * 2;
-                    if (row < n_rows) g[c] = *reinterpret_cast<const double2*>(wstage + row * kArPad + col);
+                for (int i = 0; i < 5; i++) {
+                    const int c = i * kWave + lane;           // 16-byte piece of the wave's 5-KiB block
+                    const int row = c / 5;
+                    if (row < n_rows) g[c] = reinterpret_cast<const double2*>(wstage)[c];   // staged rows are contiguous (pad = row)
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -135,6 +174,29 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
 #pragma unroll
         for (int w = 0; w < kTileThreads / kWave; w++) sum += red[w * kTileVals + tid];
         tile_part[(size_t)blockIdx.x * kTileVals + tid] = sum;
+    }
+}
+
+// Read-back for the parity tests only: the loss-corrected residual and the full Jacobian blocks of every observation,
+// exactly as ba_linearize forms them in registers before it folds them into the compact row.
+__global__ __launch_bounds__(kTileThreads) void ba_debug_rows_kernel(
+    const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
+    const double* __restrict__ campre, const double* __restrict__ pts, const int32_t* __restrict__ cam_free,
+    const Proj P, const double delta, double* __restrict__ r_out, double* __restrict__ jc_out, double* __restrict__ jp_out)
+{
+    const Tile t = tiles[blockIdx.x];
+    const bool fixed = cam_free[t.cam] < 0;
+    PosePre pr;
+    pose_load(campre + kPoseStride * (size_t)t.cam, pr);
+    for (uint32_t o = threadIdx.x; o < t.count; o += kTileThreads) {
+        const size_t k = (size_t)t.start + o;
+        const uint32_t p = obs_pt[k];
+        const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+        double r[4], jc[24], jp[12];
+        (void)residual_jacobian(pr, x, uv[k], P, delta, fixed, r, jc, jp);
+        for (int i = 0; i < 4; i++) r_out[4 * k + i] = r[i];
+        for (int i = 0; i < 24; i++) jc_out[24 * k + i] = jc[i];
+        for (int i = 0; i < 12; i++) jp_out[12 * k + i] = jp[i];
     }
 }
 
@@ -249,18 +311,21 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n
         for (uint32_t q = pt_start[p] + sub; q < pt_start[p + 1]; q += kBacksubLanes) {
             const double2* row = reinterpret_cast<const double2*>(ar + kArRow * (size_t)pt_obs[q]);
             const double* Rc = campre + kPoseStride * (size_t)q_cam[q];
-            double w[16], R[10], jp[12];
+            double w[10], R[10], z[9];
 #pragma unroll
-            for (int i = 0; i < 8; i++) { const double2 d = row[i]; w[2 * i] = d.x; w[2 * i + 1] = d.y; }
+            for (int i = 0; i < 5; i++) { const double2 d = row[i]; w[2 * i] = d.x; w[2 * i + 1] = d.y; }
 #pragma unroll
             for (int i = 0; i < 5; i++) { const double2 d = reinterpret_cast<const double2*>(Rc)[i]; R[2 * i] = d.x; R[2 * i + 1] = d.y; }
-            compact_jp(w, R, jp);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const double a = jp[i * 3], b = jp[i * 3 + 1], c = jp[i * 3 + 2], r = w[12 + i];
-                c0 += a * a; c1 += a * b; c2 += a * c; c3 += b * b; c4 += b * c; c5 += c * c;
-                g0 += a * r; g1 += b * r; g2 += c * r;
-            }
+            compact_gr(w, R, z);                       // Z = G R;  J_p^T J_p = R^T Z,  J_p^T r = R^T h
+            c0 += R[0] * z[0] + R[3] * z[3] + R[6] * z[6];
+            c1 += R[0] * z[1] + R[3] * z[4] + R[6] * z[7];
+            c2 += R[0] * z[2] + R[3] * z[5] + R[6] * z[8];
+            c3 += R[1] * z[1] + R[4] * z[4] + R[7] * z[7];
+            c4 += R[1] * z[2] + R[4] * z[5] + R[7] * z[8];
+            c5 += R[2] * z[2] + R[5] * z[5] + R[8] * z[8];
+            g0 += R[0] * w[6] + R[3] * w[7] + R[6] * w[8];
+            g1 += R[1] * w[6] + R[4] * w[7] + R[7] * w[8];
+            g2 += R[2] * w[6] + R[5] * w[7] + R[8] * w[8];
         }
     }
 #pragma unroll
@@ -293,10 +358,10 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_scale_kernel(uint32_t n_
 // rows for cameras that do not see it) is a GEMM over the concatenated point columns, and it runs on the f64 matrix
 // cores.  W~ is J_c^T J_p without the per-camera factor T = blockdiag(M^T, I) (ba_device.h): ba_schur_reduce applies T
 // once per block.  Per batch (<= 256 observations, <= PB points):
-//   * all lanes fetch the A part (96 B) of the batch's compact rows from HBM as 16-byte pieces - requested a whole
+//   * all lanes fetch the G part (48 B) of the batch's compact rows from HBM as 16-byte pieces - requested a whole
 //     batch AHEAD, into registers - and park them in LDS;
 //   * one lane per point inverts the damped 3x3 block of the NEXT batch's points in registers; two lanes per
-//     observation form W~ and Y~ = W~ Cinv from A, the camera's rotation (an LDS table of the chunk's window cameras)
+//     observation form W~ and Y~ = W~ Cinv from G, the camera's rotation (an LDS table of the chunk's window cameras)
 //     and the point, and write them into two zero-filled LDS images laid out [point column][window row];
 //   * every wave owns a fixed set of 16x16 tiles of the window's upper triangle and accumulates
 //     v_mfma_f64_16x16x4_f64 products over the batch's columns in registers (no atomics, fixed order); lane groups
@@ -304,7 +369,7 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_scale_kernel(uint32_t n_
 // The chunk's window goes to its own slab ([pair a <= b][6x6] then [camera][6]); ba_schur_reduce sums the slabs
 // per block in a fixed order, so the reduced camera system is bitwise reproducible.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kRawRow = 12;                       // A: 4x3 doubles staged per observation
+constexpr int kRawRow = 6;                        // G: the first 48 B of the compact row staged per observation
 constexpr int kRawPieces = kRawRow / 2;           // 16-byte pieces per row
 constexpr int kSchurThreads = 512;
 constexpr int kCamTab = 10;                       // per window camera: R (9), first-order-branch flag
@@ -388,7 +453,7 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
     constexpr int kRhsGroups = KMAX <= 16 ? 4 : 2;   // kRhsGroups * 6 KMAX <= NT lanes share the rhs product
     double racc = 0.0;   // partial rhs of row tid % rows_used
 
-    // Prefetch registers, one batch ahead: this lane's 16-byte pieces of the A part of the batch's compact rows; its
+    // Prefetch registers, one batch ahead: this lane's 16-byte pieces of the G part of the batch's compact rows; its
     // observation's point id and window slot; and - one lane per point - the point's J_p^T J_p, Jacobi scale, J_p^T r
     // and position.  Everything that does not depend on the batch is worked out once, here; row offsets are 32-bit
     // (the host refuses problems whose row array exceeds 4 GiB).
@@ -491,18 +556,17 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
             const int o = tid >> 1, half = tid & 1;
             const int slot = slot_l[o];
             if (slot != 255) {
-                const double* A = raw + o * kRawRow;
+                const double* Gr = raw + o * kRawRow;
                 const int pl = pt_l[o];
                 const double* ci = cil_b + pl * 6;
                 const double* ct = camtab + slot * kCamTab;
-                double Am[12], R[9], jp[12], v[3], w[18];
+                double G[6], R[9], v[3], w[18];
 #pragma unroll
-                for (int i = 0; i < 12; i++) Am[i] = A[i];
+                for (int i = 0; i < 6; i++) G[i] = Gr[i];
 #pragma unroll
                 for (int i = 0; i < 9; i++) R[i] = ct[i];
                 compact_v(R, ct[9] != 0.0, xl_b + pl * 3, v);
-                compact_jp(Am, R, jp);
-                compact_wt(Am, jp, v, w);
+                compact_wt(G, R, v, w);
                 const double c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3], c4 = ci[4], c5 = ci[5];
                 double* Wc = Wi + (pl * 3) * LD + slot * 6;
                 double* Yc = Yi + (pl * 3) * LD + slot * 6;
@@ -625,14 +689,13 @@ __global__ __launch_bounds__(64) void ba_long_prepare_kernel(const LongPoint* __
     for (uint32_t lo = lp.lo_begin + threadIdx.x; lo < lp.lo_end; lo += 64) {
         const double* a = ar + kArRow * (size_t)lo_row[lo];
         const double* pc = campre + kPoseStride * (size_t)lo_cam[lo];
-        double A[12], R[9], jp[12], v[3], w[18];
+        double G[6], R[9], v[3], w[18];
 #pragma unroll
-        for (int i = 0; i < 12; i++) A[i] = a[i];
+        for (int i = 0; i < 6; i++) G[i] = a[i];
 #pragma unroll
         for (int i = 0; i < 9; i++) R[i] = pc[i];
         compact_v(R, pc[21] != 0.0, x, v);
-        compact_jp(A, R, jp);
-        compact_wt(A, jp, v, w);
+        compact_wt(G, R, v, w);
         double* out = wy + 36 * (size_t)lo;
         double* cam = slab + lo_cam_off[lo];
 #pragma unroll
@@ -806,7 +869,7 @@ __global__ __launch_bounds__(1024) void ba_cam_update_kernel(uint32_t n_cam, con
 // K8  back-substitution dp = -Cinv (g_p + sum_obs J_p^T (J_c dc)), candidate point with the box bounds,
 // per-workgroup partials {model-cost share, |step|^2, |x|^2, g.step, max|g|}.
 // From the compact rows: J_c dc = A u with u = w x v + dc_t (w = M dc_rot per camera, from ba_cam_update; v = R x or x),
-// J_p^T (A u) = R^T (A^T (A u)).
+// J_p^T (A u) = R^T (G u).
 __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
     uint32_t n_pt, const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_obs,
     const uint32_t* __restrict__ q_cam, const double* __restrict__ ar, const double* __restrict__ campre,
@@ -832,9 +895,9 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
             const double2* row = reinterpret_cast<const double2*>(ar + kArRow * k);
             const double* pc = campre + kPoseStride * cam;
             const double* d = dcw + 6 * cam;
-            double A[12], R[10];
+            double G[6], R[10];
 #pragma unroll
-            for (int i = 0; i < 6; i++) { const double2 v2 = row[i]; A[2 * i] = v2.x; A[2 * i + 1] = v2.y; }
+            for (int i = 0; i < 3; i++) { const double2 v2 = row[i]; G[2 * i] = v2.x; G[2 * i + 1] = v2.y; }
 #pragma unroll
             for (int i = 0; i < 5; i++) { const double2 v2 = reinterpret_cast<const double2*>(pc)[i]; R[2 * i] = v2.x; R[2 * i + 1] = v2.y; }
             const bool small = pc[21] != 0.0;
@@ -842,12 +905,9 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
             double v[3];
             compact_v(R, small, x, v);
             const double u0 = w1 * v[2] - w2 * v[1] + d3, u1 = w2 * v[0] - w0 * v[2] + d4, u2 = w0 * v[1] - w1 * v[0] + d5;
-            double z0 = 0.0, z1 = 0.0, z2 = 0.0;     // A^T (A u)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const double m = A[i * 3] * u0 + A[i * 3 + 1] * u1 + A[i * 3 + 2] * u2;
-                z0 += A[i * 3] * m; z1 += A[i * 3 + 1] * m; z2 += A[i * 3 + 2] * m;
-            }
+            const double z0 = G[0] * u0 + G[1] * u1 + G[2] * u2;     // G u = A^T (A u)
+            const double z1 = G[1] * u0 + G[3] * u1 + G[4] * u2;
+            const double z2 = G[2] * u0 + G[4] * u1 + G[5] * u2;
             t0 += R[0] * z0 + R[3] * z1 + R[6] * z2;
             t1 += R[1] * z0 + R[4] * z1 + R[7] * z2;
             t2 += R[2] * z0 + R[5] * z1 + R[8] * z2;
@@ -910,6 +970,15 @@ void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const 
     if (!n_tiles) return;
     hipLaunchKernelGGL(ba_linearize_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre, pts,
                        cam_free, P, delta, ar, tile_part);
+}
+
+void launch_debug_rows(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
+                       const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
+                       double* r_out, double* jc_out, double* jp_out)
+{
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(ba_debug_rows_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre, pts, cam_free, P, delta,
+                       r_out, jc_out, jp_out);
 }
 
 void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,

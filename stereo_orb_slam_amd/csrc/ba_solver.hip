@@ -1282,41 +1282,19 @@ int soslam_ba_debug_read(soslam_ba* h, int32_t what, void* dst, uint64_t bytes)
     case SOSLAM_DBG_RESIDUALS:
     case SOSLAM_DBG_JAC_POINT:
     case SOSLAM_DBG_JAC_CAM: {
-        // the device keeps compact rows [A | r]; J_p = A R and J_c = [A D | A], D = -[v]x M, are rebuilt here exactly as the
-        // kernels rebuild them (ba_device.h), from the pose table and the points of the linearisation point
+        // the device keeps compact rows [G | h]; the blocks the tests compare are formed again by a read-back kernel
+        // with the arithmetic of ba_linearize, at the linearisation point (pose table and points it was made from)
         const size_t w = what == SOSLAM_DBG_RESIDUALS ? 4 : (what == SOSLAM_DBG_JAC_POINT ? 12 : 24);
         SOSLAM_CHECK(need(n_obs * w * sizeof(double)));
-        std::vector<double> rows(n_obs * kArRow), pre((size_t)h->n_cam * kPoseStride), pts((size_t)h->n_pt * 3);
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(rows.data(), h->ar.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(pre.data(), h->campre.p, pre.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(pts.data(), h->pts[h->cur].p, pts.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        DevBuf<double> dr, djc, djp;
+        SOSLAM_CHECK(dr.alloc(n_obs * 4)); SOSLAM_CHECK(djc.alloc(n_obs * 24)); SOSLAM_CHECK(djp.alloc(n_obs * 12));
+        launch_debug_rows(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p, h->proj,
+                          h->opt.huber_delta, dr.p, djc.p, djp.p);
+        std::vector<double> tmp(n_obs * w);
+        const double* src = what == SOSLAM_DBG_RESIDUALS ? dr.p : (what == SOSLAM_DBG_JAC_POINT ? djp.p : djc.p);
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
         SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
-        for (size_t i = 0; i < n_obs; i++) {
-            const double* A = &rows[i * kArRow];
-            double* o = out + w * h->obs_int2user[i];
-            if (what == SOSLAM_DBG_RESIDUALS) { std::memcpy(o, A + 12, 4 * sizeof(double)); continue; }
-            const uint32_t cam = h->h_obs_cam[i];
-            const double* R = &pre[(size_t)cam * kPoseStride];
-            const double* M = R + 9;
-            if (what == SOSLAM_DBG_JAC_POINT) {
-                for (int k = 0; k < 4; k++)
-                    for (int j = 0; j < 3; j++) o[k * 3 + j] = A[k * 3] * R[j] + A[k * 3 + 1] * R[3 + j] + A[k * 3 + 2] * R[6 + j];
-                continue;
-            }
-            if (h->h_cam_free[cam] < 0) { std::memset(o, 0, 24 * sizeof(double)); continue; }
-            const double* x = &pts[3 * (size_t)h->h_obs_pt[i]];
-            double v[3], D[9];
-            for (int k = 0; k < 3; k++) v[k] = R[21] != 0.0 ? x[k] : R[k * 3] * x[0] + R[k * 3 + 1] * x[1] + R[k * 3 + 2] * x[2];
-            for (int j = 0; j < 3; j++) {
-                D[0 * 3 + j] = -(v[1] * M[2 * 3 + j] - v[2] * M[1 * 3 + j]);
-                D[1 * 3 + j] = -(v[2] * M[0 * 3 + j] - v[0] * M[2 * 3 + j]);
-                D[2 * 3 + j] = -(v[0] * M[1 * 3 + j] - v[1] * M[0 * 3 + j]);
-            }
-            for (int k = 0; k < 4; k++) {
-                for (int j = 0; j < 3; j++) o[k * 6 + j] = A[k * 3] * D[j] + A[k * 3 + 1] * D[3 + j] + A[k * 3 + 2] * D[6 + j];
-                o[k * 6 + 3] = A[k * 3]; o[k * 6 + 4] = A[k * 3 + 1]; o[k * 6 + 5] = A[k * 3 + 2];
-            }
-        }
+        for (size_t i = 0; i < n_obs; i++) std::memcpy(out + w * h->obs_int2user[i], &tmp[i * w], w * sizeof(double));
         return SOSLAM_OK;
     }
     case SOSLAM_DBG_COST:
