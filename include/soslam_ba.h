@@ -217,7 +217,7 @@ void soslam_ba_shard_range(uint32_t n_pt, int32_t rank, int32_t world, uint32_t*
 /* ---- stage-level access: parity tests, roofline measurement ------------------------------------------ */
 
 enum {
-    SOSLAM_KERNEL_LINEARIZE = 0,     /* ba_linearize: reads 48 B, writes the compact row [A | r] = 128 B per observation */
+    SOSLAM_KERNEL_LINEARIZE = 0,     /* ba_linearize: reads 48 B, writes the compact row [A^T A | A^T r] = 80 B per observation */
     SOSLAM_KERNEL_COST = 1,          /* ba_cost: residual + loss only (48 B / observation) */
     SOSLAM_KERNEL_POINT_REDUCE = 2,
     SOSLAM_KERNEL_SCHUR = 3,

@@ -3,9 +3,9 @@
 // Data layout in HBM:
 //   uv      [n_obs] float4          camera-major observation order (bucketed by camera)
 //   obs_pt  [n_obs] u32             internal point id (points sorted by first camera)
-//   ar      [n_obs][16] f64         compact Jacobian row [A (4x3) | r (4)], 128-B rows, camera-major like uv; J_p = A R and
-//                                   J_c = [A D | A] are rebuilt by the consumers (ba_device.h); point-major passes
-//                                   gather whole rows through the pt_obs index
+//   ar      [n_obs][10] f64         compact row [G = A^T A (6) | h = A^T r (3) | 0], 80-B rows, camera-major like uv;
+//                                   the products of J_p = A R and J_c = [A D | A] are rebuilt from it by the consumers
+//                                   (ba_device.h); point-major passes gather rows through the pt_obs index
 //   C/gp    [n_pt][6] / [n_pt][3]   per-point J_p^T J_p (xx xy xz yy yz zz) and J_p^T r
 //   S       [n_blocks][36]          upper block-sparse reduced camera matrix (6x6 row-major blocks)
 // The kernels are HBM-bound streaming / gather work at a few flop/B; the one GEMM-shaped piece, the Schur window
