@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
     import torch
     import torch.distributed as dist
 
@@ -30,7 +30,10 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     full = synth.generate_ba(2)
     with ba.BundleAdjustment(ba.default_options(device=0, linear_solver=2)) as h:   # the library's own stream
         distributed.load_shard(h, full, rank, world)
@@ -72,3 +75,27 @@ def test_two_ranks_follow_the_single_rank_trajectory(tmp_path):
         assert r0["accepted"].all()
         np.testing.assert_allclose(r0["cost"], ref_cost, rtol=1e-9)
         assert np.abs(r0["cams"] - ref_cams).max() < 1e-8
+
+
+def test_rccl_device_allreduce_one_rank(tmp_path):
+    """The RCCL leg of the callback (backend nccl, in-place all-reduce of a device sub-range on the library's own
+    stream) with the one rank a one-GPU box allows: a process group of size 1 still goes through RCCL's launch path,
+    its stream ordering against the library's kernels and the aliasing of the reduce buffer.  The trajectory must be the
+    plain single-handle one, bitwise."""
+    import torch
+    import torch.multiprocessing as mp
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no fallback")
+    from stereo_orb_slam_amd import ba, synth
+
+    full = synth.generate_ba(2)
+    with ba.BundleAdjustment(ba.default_options(device=0, linear_solver=2)) as h:
+        h.load(full)
+        h.iterate(ITERS)
+        ref_cost = np.array([it.cost for it in h.iteration_log()])
+        ref_cams, _ = h.get_state()
+    mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), "nccl"), nprocs=1, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    assert r0["accepted"].all()
+    assert np.array_equal(r0["cost"], ref_cost) and np.array_equal(r0["cams"], ref_cams)
