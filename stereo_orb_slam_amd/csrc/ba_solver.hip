@@ -929,8 +929,8 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         }
         h->log.push_back(e);
         if (o.verbose)
-            printf("%4d  cost %.9e  cand %.9e  model %.3e  rho %.3e  |step| %.3e  radius %.3e  lin_it %d  %s\n", it, sc.x_cost,
-                   sc.cand_cost, sc.mcc, rel, sc.step_norm, radius, sc.lin_iters, e.accepted ? "accepted" : "rejected");
+            printf("%4d  cost %.9e  cand %.9e  model %.3e  rho %.3e  |step| %.3e  radius %.3e  lin_it %d  lin_res %.2e  %s\n", it, sc.x_cost,
+                   sc.cand_cost, sc.mcc, rel, sc.step_norm, radius, sc.lin_iters, h->host_scal[SC_LIN_RESID], e.accepted ? "accepted" : "rejected");
     }
     SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
     sum.iterations = it;

@@ -133,97 +133,121 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 // Eliminated node i = h (2 j + 1)  (or node 0 when final != 0): E_i = D_i^-1 by a block Gauss-Jordan sweep.
 // Sweeping the 3x3 pivot block K of a matrix turns   A_KK -> A_KK^-1,  A_Kj -> A_KK^-1 A_Kj,  A_iK -> -A_iK A_KK^-1,
 // A_ij -> A_ij - A_iK A_KK^-1 A_Kj;  after all 2 bw pivot blocks the array holds A^-1.
-// The matrix lives in REGISTERS: wave jb owns the 6-column segment jb, lane = row, six doubles per lane.  What a
-// step costs is the instruction stream of its slowest wave, so the shared part is done once: the wave that owns the
-// pivot columns takes the pivot block from its own lanes (v_readlane), inverts it in closed form, and publishes
-// G = A_iK A_KK^-1 (rows of -A_KK^-1 on the pivot rows) through a double-buffered LDS strip - one barrier per pivot
-// block.  Every wave then reads its three G values and takes the pivot rows A_Kj of its own segment from its own
-// lanes (v_readlane again, no LDS).
-constexpr int kCrInvertThreadsMax = 64 * kCrBandMax;
+//
+// The matrix (padded to 64 x 64) lives in the ACCUMULATOR registers of the f64 matrix cores: wave ti of four owns the
+// tile row ti, four 16x16 tiles, D[i = 4 r + l/16][j = l%16] per tile.  A step is one rank-3 (padded to 4) update
+// new = base + A' B on v_mfma_f64_16x16x4_f64 - four matrix instructions per wave instead of eighteen vector FMAs
+// plus the cross-lane traffic that feeds them, and one wave per SIMD instead of nine on four:
+//   * the waves that hold the pivot rows a = A_K: copy them to an LDS strip (the only exchange, one barrier per step);
+//   * the sweep keeps the matrix symmetric up to the sign of the swept/unswept cross blocks, so the pivot COLUMNS need
+//     no second exchange: A_iK = s_i a_i^T with s_i = -1 on rows swept earlier, +1 otherwise;
+//   * every wave inverts the pivot block itself (closed form, redundant but off the other waves' critical path) and
+//     forms its operands: A'[i][k] = -s_i a[k][i] (e_c on pivot row c), B[k][j] = (P^-1 a)[k][j] (P^-1[k][c] on pivot
+//     column c); base = the tile with the pivot rows and columns zeroed.  Then pivot rows become P^-1 a, pivot columns
+//     -A_iK P^-1, the pivot block P^-1, everything else A_ij - A_iK P^-1 A_Kj.
+constexpr int kCrInvertThreads = 256;
 
-__global__ __launch_bounds__(kCrInvertThreadsMax) void cr_invert_kernel(const CrView v, const uint32_t h, const int final_node,
-                                                                        double* __restrict__ scal)
+template <int NSTEPS>
+__global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrView v, const uint32_t h, const int final_node,
+                                                                     double* __restrict__ scal)
 {
-    extern __shared__ double lds[];
-    const int sb = v.sb, bw = v.bw, ld = sb | 1;
-    const int row = threadIdx.x % 64, jb = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);   // blockDim = 64 bw
+    __shared__ double strips[2][4][64];   // [buffer][pivot row c, 3 = zeros][column]
+    __shared__ double X[64 * kLd];
+    const int sb = v.sb;
+    const int lane = threadIdx.x % 64, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    const int lr = lane % 16, lk = lane / 16;
     const size_t sb2 = (size_t)sb * sb;
-    const uint32_t i = final_node ? 0u : h * (2 * blockIdx.x + 1);
-    if (i >= v.m) return;
-    double* X = lds;                          // sb x ld staging image (odd row stride: conflict-free column access)
-    double* pc = lds + (size_t)sb * ld;       // [2][64][3] strips of G
-    const bool live = row < sb;
-    {
-        // coalesced: wave jb takes rows jb, jb + bw, ..; every load is issued before the first LDS write
-        const double* src = v.D + i * sb2;
-        double tmp[6];
-#pragma unroll
-        for (int u = 0; u < 6; u++) tmp[u] = live ? src[(size_t)(jb + u * bw) * sb + row] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 6; u++) if (live) X[(jb + u * bw) * ld + row] = tmp[u];
-    }
-    __syncthreads();
-    double x[6];
-#pragma unroll
-    for (int cc = 0; cc < 6; cc++) x[cc] = live ? X[row * ld + jb * 6 + cc] : 0.0;
+    const uint32_t node = final_node ? 0u : h * (2 * blockIdx.x + 1);
+    if (node >= v.m) return;
 
+    double4_t acc[4];
+    {
+        const double* src = v.D + node * sb2;
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * wave + 4 * r + lk, j = 16 * tj + lr;
+                acc[tj][r] = (i < sb && j < sb) ? src[(size_t)i * sb + j] : (i == j ? 1.0 : 0.0);   // identity padding: extra steps are harmless
+            }
+    }
+
+    // Lane group lk = l/16 feeds k = lk of both operands; group 3 (the padding k = 3) reads a strip row of zeros.
+    const int zr0 = (lk < 3 ? 0 : 3) * 64, zr1 = (lk < 3 ? 1 : 3) * 64, zr2 = (lk < 3 ? 2 : 3) * 64;
+    if (threadIdx.x < 128) strips[threadIdx.x / 64][3][threadIdx.x % 64] = 0.0;
     bool ok = true;
-    int buf = 0;
-    for (int kb = 0; kb < 2 * bw; kb++) {
-        const int k0 = kb * 3, jbk = k0 / 6;
-        const bool second = (k0 - jbk * 6) != 0;   // pivot columns are x[3..5] (else x[0..2]) of wave jbk
-        const bool pwave = jb == jbk;
-        double* strip = pc + buf * 192;
-        if (pwave) {
-            const double p0 = second ? x[3] : x[0], p1 = second ? x[4] : x[1], p2 = second ? x[5] : x[2];
-            // pivot block = rows k0..k0+2 of the pivot columns: lanes k0..k0+2 of this wave
-            const double m[6] = {readlane_f64(p0, k0), readlane_f64(p1, k0), readlane_f64(p2, k0),
-                                 readlane_f64(p1, k0 + 1), readlane_f64(p2, k0 + 1), readlane_f64(p2, k0 + 2)};
-            double Pi[6];
-            ok = sym3_inverse(m, Pi) && ok;     // xx xy xz yy yz zz
-            const int r = row - k0;             // 0..2 on a pivot row
-            const bool prow = r >= 0 && r < 3;
-            // G row = a Pi with a = A_iK, or -e_r on a pivot row (so that the row is -Pi[r][:])
-            const double a0 = prow ? (r == 0 ? -1.0 : 0.0) : p0;
-            const double a1 = prow ? (r == 1 ? -1.0 : 0.0) : p1;
-            const double a2 = prow ? (r == 2 ? -1.0 : 0.0) : p2;
-            strip[row * 3 + 0] = a0 * Pi[0] + a1 * Pi[1] + a2 * Pi[2];
-            strip[row * 3 + 1] = a0 * Pi[1] + a1 * Pi[3] + a2 * Pi[4];
-            strip[row * 3 + 2] = a0 * Pi[2] + a1 * Pi[4] + a2 * Pi[5];
+#pragma unroll
+    for (int kb = 0; kb < NSTEPS; kb++) {   // straight-line code: every register index below is static
+        const int k0 = 3 * kb;
+        double* strip = &strips[kb & 1][0][0];
+        // pivot rows -> LDS (row k0 + c lives in wave (k0+c)/16, accumulator register ((k0+c)%16)/4, lane group (k0+c)%4)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int row = k0 + c;
+            if (wave == row / 16 && lk == row % 4) {
+#pragma unroll
+                for (int tj = 0; tj < 4; tj++) strip[c * 64 + 16 * tj + lr] = acc[tj][(row % 16) / 4];
+            }
         }
         __syncthreads();
-        const double g0 = strip[row * 3 + 0], g1 = strip[row * 3 + 1], g2 = strip[row * 3 + 2];
-        const bool prow = row >= k0 && row < k0 + 3;
-        // x = base - g Z with Z = A_Kj from this wave's own lanes, base = A_ij (zero on the pivot rows); branch-free.
-        // The pivot columns (three registers of the pivot wave) are then overwritten with -g.
+        // Every lane inverts the same block with the same operations: P^-1 must be the SAME symmetric matrix in all
+        // lane groups (rows taken from differently rounded inverses make the sweep inconsistent - measured: four
+        // digits of the factor lost).  r0 r1 r2 = row lk of P^-1.
+        const double m[6] = {strip[k0], strip[k0 + 1], strip[k0 + 2], strip[64 + k0 + 1], strip[64 + k0 + 2], strip[128 + k0 + 2]};
+        double Pi[6];
+        ok = sym3_inverse(m, Pi) && ok;     // xx xy xz yy yz zz
+        const double r0 = lk == 0 ? Pi[0] : lk == 1 ? Pi[1] : Pi[2];
+        const double r1 = lk == 0 ? Pi[1] : lk == 1 ? Pi[3] : Pi[4];
+        const double r2 = lk == 0 ? Pi[2] : lk == 1 ? Pi[4] : Pi[5];
+        // A'[i][k = lk], i = 16 wave + lr
+        double aop;
+        {
+            const int i = 16 * wave + lr, ci = i - k0;
+            const double av = strip[lk * 64 + i];
+            aop = i < k0 ? av : -av;
+            if (ci >= 0 && ci < 3) aop = lk == ci ? 1.0 : 0.0;
+        }
 #pragma unroll
-        for (int cc = 0; cc < 6; cc++) {
-            const double z0 = readlane_f64(x[cc], k0 + 0);
-            const double z1 = readlane_f64(x[cc], k0 + 1);
-            const double z2 = readlane_f64(x[cc], k0 + 2);
-            const double base = prow ? 0.0 : x[cc];
-            x[cc] = base - (g0 * z0 + g1 * z1 + g2 * z2);
+        for (int tj = 0; tj < 4; tj++) {
+            const int j = 16 * tj + lr;
+            double bop = r0 * strip[zr0 + j] + r1 * strip[zr1 + j] + r2 * strip[zr2 + j];
+            double4_t base = acc[tj];
+            const bool tile_has_pcol = k0 + 2 >= 16 * tj && k0 < 16 * tj + 16;   // static
+            if (tile_has_pcol) {
+                const int cj = j - k0;
+                if (cj >= 0 && cj < 3) {
+                    bop = lk == 3 ? 0.0 : (cj == 0 ? r0 : cj == 1 ? r1 : r2);
+                    base = double4_t{0.0, 0.0, 0.0, 0.0};
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int row = k0 + c;
+                if (wave == row / 16 && lk == row % 4) base[(row % 16) / 4] = 0.0;   // static register index
+            }
+            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, base, 0, 0, 0);
         }
-        if (pwave) {
-            if (second) { x[3] = -g0; x[4] = -g1; x[5] = -g2; }
-            else        { x[0] = -g0; x[1] = -g1; x[2] = -g2; }
-        }
-        buf ^= 1;
     }
-    if (!ok && row == 0) scal[SC_LIN_STATUS] = 1.0;
-    // symmetric to rounding; store the symmetrised inverse (coalesced, through the staging image)
-    __syncthreads();
+    if (!ok && threadIdx.x == 0) scal[SC_LIN_STATUS] = 1.0;
+    // symmetric to rounding; store the symmetrised inverse (coalesced, through an LDS image)
 #pragma unroll
-    for (int cc = 0; cc < 6; cc++) if (live) X[row * ld + jb * 6 + cc] = x[cc];
-    __syncthreads();
-    if (live) {
-        double* dst = v.E + i * sb2;
+    for (int tj = 0; tj < 4; tj++)
 #pragma unroll
-        for (int u = 0; u < 6; u++) {
-            const int r2 = jb + u * bw;
-            dst[(size_t)r2 * sb + row] = 0.5 * (X[r2 * ld + row] + X[row * ld + r2]);
-        }
-    }
+        for (int r = 0; r < 4; r++) X[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr] = acc[tj][r];
+    __syncthreads();
+    double* dst = v.E + node * sb2;
+    for (int i = wave; i < sb; i += kCrInvertThreads / 64)
+        if (lane < sb) dst[(size_t)i * sb + lane] = 0.5 * (X[i * kLd + lane] + X[lane * kLd + i]);
+}
+
+// 2 bw pivot blocks, rounded up to the next instantiated step count (the identity padding makes extra steps no-ops)
+void launch_cr_invert(hipStream_t s, uint32_t grid, const CrView& v, uint32_t h, int final_node, double* scal)
+{
+    static_assert(kCrBandMax == 10, "step counts below cover bw <= 10 (20 pivot blocks of a 64 x 64 register image)");
+    if (v.bw <= 3) hipLaunchKernelGGL(cr_invert_kernel<6>, dim3(grid), dim3(kCrInvertThreads), 0, s, v, h, final_node, scal);
+    else if (v.bw <= 6) hipLaunchKernelGGL(cr_invert_kernel<12>, dim3(grid), dim3(kCrInvertThreads), 0, s, v, h, final_node, scal);
+    else if (v.bw <= 9) hipLaunchKernelGGL(cr_invert_kernel<18>, dim3(grid), dim3(kCrInvertThreads), 0, s, v, h, final_node, scal);
+    else hipLaunchKernelGGL(cr_invert_kernel<20>, dim3(grid), dim3(kCrInvertThreads), 0, s, v, h, final_node, scal);
 }
 
 // Remaining node k = 2 h j, column tile q = blockIdx.y (16 columns of every product), one wave per 16-row tile.
@@ -473,16 +497,14 @@ void launch_cr_factor(hipStream_t s, const BsrView& A, uint32_t n_blocks, const 
     const uint32_t pad = v.m * (uint32_t)bw - A.n_rows;
     hipLaunchKernelGGL(cr_assemble_kernel, dim3(n_blocks + pad), dim3(64), 0, s, A.blocks, blk_row, blk_col, n_blocks, A.n_rows, v);
     const size_t kp = ((size_t)v.sb + 3) & ~(size_t)3;
-    const size_t lds_i = sizeof(double) * ((size_t)v.sb * (v.sb | 1) + 2 * 192);
     const size_t lds_r = sizeof(double) * 4 * kp * kLd;
-    if (lds_i > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_invert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_i);
     if (lds_r > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
     const uint32_t nt = ((uint32_t)v.sb + 15) / 16;
     for (uint32_t h = 1; h < v.m; h *= 2) {
-        hipLaunchKernelGGL(cr_invert_kernel, dim3(count_odd(v.m, h)), dim3(64 * bw), lds_i, s, v, h, 0, scal);
+        launch_cr_invert(s, count_odd(v.m, h), v, h, 0, scal);
         hipLaunchKernelGGL(cr_reduce_kernel, dim3(count_even(v.m, h), nt), dim3(kCrReduceThreads), lds_r, s, v, h);
     }
-    hipLaunchKernelGGL(cr_invert_kernel, dim3(1), dim3(64 * bw), lds_i, s, v, 0u, 1, scal);
+    launch_cr_invert(s, 1, v, 0u, 1, scal);
 }
 
 void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const double* b, double* x, const double* done_flag)
