@@ -387,16 +387,17 @@ __device__ __forceinline__ double group_sum(double part, double (*red)[64], int 
 
 struct ColOp { double m[kCrSolveIters], y[kCrSolveIters]; };
 
-// request M[m][t] and y[m] for m = g, g + 8, ..
-__device__ __forceinline__ void col_load(ColOp& o, const double* __restrict__ M, const double* __restrict__ y, int sb, int t, int g,
-                                         bool on)
+// request M[m][t] and y[y0 + m] for m = g, g + 8, ..; the vector has n_y valid entries and reads as zero beyond them
+// (the right-hand side of a solve is the caller's unpadded vector on first touch, the padded work vector afterwards)
+__device__ __forceinline__ void col_load(ColOp& o, const double* __restrict__ M, const double* __restrict__ y, size_t y0, uint32_t n_y,
+                                         int sb, int t, int g, bool on)
 {
 #pragma unroll
     for (int u = 0; u < kCrSolveIters; u++) {
         const int m = g + u * kCrSolveGroups;
         const bool in = on && m < sb && t < sb;
         o.m[u] = in ? M[(size_t)m * sb + t] : 0.0;
-        o.y[u] = in ? y[m] : 0.0;
+        o.y[u] = (in && y0 + m < n_y) ? y[y0 + m] : 0.0;
     }
 }
 
@@ -408,8 +409,10 @@ __device__ __forceinline__ double col_dot(const ColOp& o)
     return s;
 }
 
-// forward, remaining node k: w_k -= Q_a^T w_a + P_c^T w_c
-__global__ __launch_bounds__(kCrSolveThreads) void cr_fwd_kernel(const CrView v, const uint32_t h, double* __restrict__ w,
+// forward, remaining node k: w_k = src_k - Q_a^T src_a - P_c^T src_c  (src = the caller's right-hand side at h = 1: no copy
+// into the work vector; = w afterwards)
+__global__ __launch_bounds__(kCrSolveThreads) void cr_fwd_kernel(const CrView v, const uint32_t h, const double* __restrict__ src,
+                                                                 const uint32_t n_src, double* __restrict__ w,
                                                                  const double* __restrict__ done_flag)
 {
     __shared__ double red[kCrSolveGroups][64];
@@ -421,47 +424,114 @@ __global__ __launch_bounds__(kCrSolveThreads) void cr_fwd_kernel(const CrView v,
     const bool has_a = k >= h, has_c = k + h < v.m;
     const uint32_t a = has_a ? k - h : 0, c = has_c ? k + h : 0;
     ColOp oa, oc;
-    col_load(oa, v.Q + a * sb2, w + (size_t)a * sb, sb, t, g, has_a);
-    col_load(oc, v.P + c * sb2, w + (size_t)c * sb, sb, t, g, has_c);
-    const double wk = (g == 0 && t < sb) ? w[(size_t)k * sb + t] : 0.0;
+    col_load(oa, v.Q + a * sb2, src, (size_t)a * sb, n_src, sb, t, g, has_a);
+    col_load(oc, v.P + c * sb2, src, (size_t)c * sb, n_src, sb, t, g, has_c);
+    const size_t ik = (size_t)k * sb + t;
+    const double wk = (g == 0 && t < sb && ik < n_src) ? src[ik] : 0.0;
     const double s = group_sum(col_dot(oa) + col_dot(oc), red, t, g);
-    if (g == 0 && t < sb) w[(size_t)k * sb + t] = wk - s;
+    if (g == 0 && t < sb) w[ik] = wk - s;
 }
 
-// backward, node i eliminated at stride h (or the last node): x_i = E_i w_i - P_i x_{i-h} - Q_i x_{i+h}
-__global__ __launch_bounds__(kCrSolveThreads) void cr_bwd_kernel(const CrView v, const uint32_t h, const int final_node,
-                                                                 double* __restrict__ w, const double* __restrict__ done_flag)
+// backward, node i eliminated at stride h: x_i = E_i own_i - P_i x_{i-h} - Q_i x_{i+h}; own = the caller's right-hand side
+// at h = 1 (those nodes were never touched by the forward sweep), w otherwise.  The result goes to w (later levels
+// read it) and straight to the caller's x.
+__global__ __launch_bounds__(kCrSolveThreads) void cr_bwd_kernel(const CrView v, const uint32_t h, const double* __restrict__ own,
+                                                                 const uint32_t n_own, double* __restrict__ w, double* __restrict__ x,
+                                                                 const uint32_t n_x, const double* __restrict__ done_flag)
 {
     __shared__ double red[kCrSolveGroups][64];
     if (cr_done(done_flag)) return;
     const int sb = v.sb, t = threadIdx.x % 64, g = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
     const size_t sb2 = (size_t)sb * sb;
-    const uint32_t i = final_node ? 0u : h * (2 * blockIdx.x + 1);
+    const uint32_t i = h * (2 * blockIdx.x + 1);
     if (i >= v.m) return;
-    const bool has_a = !final_node && i >= h, has_c = !final_node && i + h < v.m;
-    const uint32_t a = has_a ? i - h : 0, c = has_c ? i + h : 0;
+    const bool has_c = i + h < v.m;
+    const uint32_t a = i - h, c = has_c ? i + h : 0;
+    const uint32_t n_w = v.m * (uint32_t)sb;
     ColOp oe, oa, oc;
-    col_load(oe, v.E + i * sb2, w + (size_t)i * sb, sb, t, g, true);   // E symmetric
-    col_load(oa, v.PT + i * sb2, w + (size_t)a * sb, sb, t, g, has_a);
-    col_load(oc, v.QT + i * sb2, w + (size_t)c * sb, sb, t, g, has_c);
+    col_load(oe, v.E + i * sb2, own, (size_t)i * sb, n_own, sb, t, g, true);   // E symmetric
+    col_load(oa, v.PT + i * sb2, w, (size_t)a * sb, n_w, sb, t, g, true);
+    col_load(oc, v.QT + i * sb2, w, (size_t)c * sb, n_w, sb, t, g, has_c);
     const double s = group_sum(col_dot(oe) - col_dot(oa) - col_dot(oc), red, t, g);
-    if (g == 0 && t < sb) w[(size_t)i * sb + t] = s;
+    if (g == 0 && t < sb) {
+        const size_t ii = (size_t)i * sb + t;
+        w[ii] = s;
+        if (ii < n_x) x[ii] = s;
+    }
 }
 
-__global__ __launch_bounds__(256) void cr_load_rhs_kernel(uint32_t n, uint32_t n_pad, const double* __restrict__ b, double* __restrict__ w,
-                                                          const double* __restrict__ done_flag)
+// The top of the tree in one launch.  At the largest stride h_top < m the forward sweep has one receiving node (0), then
+// node 0 is solved, then the backward sweep has one node (h_top): three dependent matrix-vector products of single
+// workgroups.  All four operators are requested up front, the vectors travel through LDS.  Arithmetic and its order
+// are those of cr_fwd_kernel / cr_bwd_kernel.  m == 1: just x_0 = E_0 src_0.
+__global__ __launch_bounds__(kCrSolveThreads) void cr_top_kernel(const CrView v, const uint32_t h_top, const double* __restrict__ src,
+                                                                 const uint32_t n_src, double* __restrict__ w, double* __restrict__ x,
+                                                                 const uint32_t n_x, const double* __restrict__ done_flag)
 {
+    __shared__ double red[kCrSolveGroups][64];
+    __shared__ double y0[64], yc[64], w0[64], x0[64];
     if (cr_done(done_flag)) return;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_pad) w[i] = i < n ? b[i] : 0.0;
-}
-
-__global__ __launch_bounds__(256) void cr_store_x_kernel(uint32_t n, const double* __restrict__ w, double* __restrict__ x,
-                                                         const double* __restrict__ done_flag)
-{
-    if (cr_done(done_flag)) return;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) x[i] = w[i];
+    const int sb = v.sb, t = threadIdx.x % 64, g = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    const size_t sb2 = (size_t)sb * sb;
+    const bool has_c = h_top < v.m;    // false only for m == 1
+    const uint32_t c = has_c ? h_top : 0;
+    double mP[kCrSolveIters], mE0[kCrSolveIters], mEc[kCrSolveIters], mPT[kCrSolveIters];
+#pragma unroll
+    for (int u = 0; u < kCrSolveIters; u++) {
+        const int m = g + u * kCrSolveGroups;
+        const bool in = m < sb && t < sb;
+        const size_t off = (size_t)m * sb + t;
+        mP[u] = (in && has_c) ? v.P[c * sb2 + off] : 0.0;
+        mE0[u] = in ? v.E[off] : 0.0;
+        mEc[u] = (in && has_c) ? v.E[c * sb2 + off] : 0.0;
+        mPT[u] = (in && has_c) ? v.PT[c * sb2 + off] : 0.0;
+    }
+    if (g == 0) {
+        const size_t i0 = t, ic = (size_t)c * sb + t;
+        y0[t] = (t < sb && i0 < n_src) ? src[i0] : 0.0;
+        yc[t] = (has_c && t < sb && ic < n_src) ? src[ic] : 0.0;
+    }
+    __syncthreads();
+    // forward: w_0 = src_0 - P_c^T src_c
+    {
+        double d = 0.0;
+#pragma unroll
+        for (int u = 0; u < kCrSolveIters; u++) { const int m = g + u * kCrSolveGroups; d += mP[u] * (m < sb ? yc[m] : 0.0); }
+        const double s = group_sum(0.0 + d, red, t, g);
+        if (g == 0) w0[t] = has_c ? y0[t] - s : y0[t];
+        __syncthreads();
+    }
+    // last node: x_0 = E_0 w_0
+    {
+        double d = 0.0;
+#pragma unroll
+        for (int u = 0; u < kCrSolveIters; u++) { const int m = g + u * kCrSolveGroups; d += mE0[u] * (m < sb ? w0[m] : 0.0); }
+        const double s = group_sum(d - 0.0 - 0.0, red, t, g);
+        if (g == 0) {
+            x0[t] = s;
+            if (t < sb) {
+                w[t] = s;
+                if ((uint32_t)t < n_x) x[t] = s;
+            }
+        }
+        __syncthreads();
+    }
+    // backward: x_c = E_c src_c - P_c x_0
+    if (has_c) {
+        double de = 0.0, da = 0.0;
+#pragma unroll
+        for (int u = 0; u < kCrSolveIters; u++) {
+            const int m = g + u * kCrSolveGroups;
+            de += mEc[u] * (m < sb ? yc[m] : 0.0);
+            da += mPT[u] * (m < sb ? x0[m] : 0.0);
+        }
+        const double s = group_sum(de - da - 0.0, red, t, g);
+        if (g == 0 && t < sb) {
+            const size_t ic = (size_t)c * sb + t;
+            w[ic] = s;
+            if (ic < n_x) x[ic] = s;
+        }
+    }
 }
 
 constexpr int kCrMats = 7;
@@ -513,15 +583,17 @@ void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const d
     const CrView v = make_view(n_rows, bw, ws);
     double* w = ws + kCrMats * (size_t)v.m * v.sb * v.sb;
     const uint32_t n = n_rows * 6, n_pad = v.m * (uint32_t)v.sb;
-    hipLaunchKernelGGL(cr_load_rhs_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, n, n_pad, b, w, done_flag);
-    uint32_t h = 1;
-    for (; h < v.m; h *= 2) hipLaunchKernelGGL(cr_fwd_kernel, dim3(count_even(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, w, done_flag);
-    hipLaunchKernelGGL(cr_bwd_kernel, dim3(1), dim3(kCrSolveThreads), 0, s, v, 0u, 1, w, done_flag);
-    for (h /= 2; h >= 1; h /= 2) {
-        hipLaunchKernelGGL(cr_bwd_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, 0, w, done_flag);
-        if (h == 1) break;
-    }
-    hipLaunchKernelGGL(cr_store_x_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, w, x, done_flag);
+    uint32_t h_top = 1;
+    while (2 * h_top < v.m) h_top *= 2;           // largest power of two below m (1 for m <= 2)
+    // no copy in, no copy out: the first level that touches a node reads the caller's b, every backward kernel writes x
+    for (uint32_t h = 1; h < h_top; h *= 2)
+        hipLaunchKernelGGL(cr_fwd_kernel, dim3(count_even(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, h == 1 ? b : w, h == 1 ? n : n_pad, w,
+                           done_flag);
+    hipLaunchKernelGGL(cr_top_kernel, dim3(1), dim3(kCrSolveThreads), 0, s, v, h_top, h_top == 1 ? b : w, h_top == 1 ? n : n_pad, w, x, n,
+                       done_flag);
+    for (uint32_t h = h_top / 2; h >= 1; h /= 2)
+        hipLaunchKernelGGL(cr_bwd_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, h == 1 ? b : w, h == 1 ? n : n_pad, w, x,
+                           n, done_flag);
 }
 
 }  // namespace soslam
