@@ -14,10 +14,10 @@ constexpr int kTileObs = 1024;       // observations per linearize/cost workgrou
 constexpr int kTileThreads = 256;    // lanes per tile: up to 4 observations each
 constexpr int kTileVals = 28;        // 21 (J_c^T J_c upper) + 6 (J_c^T r) + 1 (rho)
 constexpr int kArRow = 10;            // f64 per observation in the compact row array [G (xx xy xz yy yz zz) | h (3) | 0], 80 B
-constexpr int kBatchObs = 256;       // observations staged per Schur batch (also the most one windowed point may have)
+constexpr int kBatchObs = 128;       // observations staged per Schur batch (also the most one windowed point may have)
 // points per Schur batch: the batch's point columns (3 each) are the k dimension of the window GEMM, and two
 // [3 PB][6 KMAX + 1] f64 images must fit LDS next to the staged rows
-constexpr int schur_batch_points(int kmax) { return kmax <= 16 ? 24 : 12; }
+constexpr int schur_batch_points(int kmax) { return 12; }
 constexpr int kPointBlock = 256;     // threads per block of the per-point kernels
 constexpr int kBacksubLanes = 4;     // lanes that share one point in ba_backsub
 constexpr uint32_t backsub_blocks(uint32_t n_pt) { return (uint32_t)(((uint64_t)n_pt * kBacksubLanes + kPointBlock - 1) / kPointBlock); }

@@ -371,7 +371,10 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_scale_kernel(uint32_t n_
 // ---------------------------------------------------------------------------------------------------
 constexpr int kRawRow = 6;                        // G: the first 48 B of the compact row staged per observation
 constexpr int kRawPieces = kRawRow / 2;           // 16-byte pieces per row
-constexpr int kSchurThreads = 512;
+// Workgroup size by window width.  Up to 16 cameras: 256 lanes and half-size batches, so that two workgroups share a
+// CU (66 KB of LDS each) and one runs while the other waits at its barriers (measured 128 -> 118 us at config 3);
+// wider windows keep 512 lanes - their 78 accumulator tiles need the registers of eight waves.
+constexpr int schur_threads(int kmax) { return kmax <= 16 ? 256 : 512; }
 constexpr int kCamTab = 10;                       // per window camera: R (9), first-order-branch flag
 
 typedef double schur_double4 __attribute__((ext_vector_type(4)));
@@ -384,7 +387,8 @@ struct SchurShape {
     static constexpr int KB = 3 * PB;                      // point columns per batch (multiple of 4)
     static constexpr int NT1 = (ROWS + 15) / 16;           // 16-wide tiles per dimension
     static constexpr int NUP = NT1 * (NT1 + 1) / 2;        // tiles of the upper triangle
-    static constexpr int TPW = (NUP + kSchurThreads / 64 - 1) / (kSchurThreads / 64);   // tiles per wave
+    static constexpr int NT = schur_threads(KMAX);         // lanes per workgroup
+    static constexpr int TPW = (NUP + NT / 64 - 1) / (NT / 64);   // tiles per wave
     static constexpr size_t lds_bytes =
         sizeof(double) * ((size_t)kBatchObs * kRawRow + 2 * (size_t)KB * LD + 2 * (PB * 6 + KB + PB * 3) + KMAX * kCamTab) + 2 * kBatchObs;
 };
@@ -400,7 +404,7 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
+__global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
     const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches, const uint32_t* __restrict__ chunk_slab,
     const uint32_t* __restrict__ chunk_cam, const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_pt,
     const uint8_t* __restrict__ q_slot, const double* __restrict__ ar, const double* __restrict__ campre,
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
     double* __restrict__ scal)
 {
     using Sh = SchurShape<KMAX>;
-    constexpr int NT = kSchurThreads, PB = Sh::PB, LD = Sh::LD, KB = Sh::KB, NT1 = Sh::NT1, NUP = Sh::NUP, TPW = Sh::TPW;
+    constexpr int NT = Sh::NT, PB = Sh::PB, LD = Sh::LD, KB = Sh::KB, NT1 = Sh::NT1, NUP = Sh::NUP, TPW = Sh::TPW;
     constexpr int NPIECE = kBatchObs * kRawPieces;                // 16-byte pieces per batch
     constexpr int PPT = (NPIECE + NT - 1) / NT;                   // per lane
     static_assert(NT >= 2 * kBatchObs, "W/Y staging uses two lanes per observation");
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(
         }
         acc[j] = schur_double4{0.0, 0.0, 0.0, 0.0};
     }
-    constexpr int kRhsGroups = KMAX <= 16 ? 4 : 2;   // kRhsGroups * 6 KMAX <= NT lanes share the rhs product
+    constexpr int kRhsGroups = 2;   // kRhsGroups * 6 KMAX <= NT lanes share the rhs product
     double racc = 0.0;   // partial rhs of row tid % rows_used
 
     // Prefetch registers, one batch ahead: this lane's 16-byte pieces of the G part of the batch's compact rows; its
@@ -1029,12 +1033,12 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
     if (kmax <= 16) {
         constexpr size_t lds = SchurShape<16>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ba_schur_kernel<16>), dim3(n_chunks), dim3(kSchurThreads), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
+        hipLaunchKernelGGL((ba_schur_kernel<16>), dim3(n_chunks), dim3(schur_threads(16)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
                            q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
     } else {
         constexpr size_t lds = SchurShape<32>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(kSchurThreads), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
+        hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(schur_threads(32)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
                            q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
     }
 }
