@@ -27,10 +27,12 @@ enum {
     SC_COST_X = 0,                                    // this rank's cost at the linearisation point
     SC_CAND_COST = 1, SC_MCC_PTS = 2, SC_STEP2_PTS = 3, SC_X2_PTS = 4, SC_GDOT_PTS = 5,  // summed over ranks
     SC_GMAX_PTS = 6,                                  // max over ranks; slots 2..6 are written as one group by sum5
-    SC_SCHUR_STATUS = 7,                              // rank-local; spread through the candidate cost (launch_status_poison)
+    // slot 7 is unused
     SC_MCC_CAM = 8, SC_STEP2_CAM = 9, SC_X2_CAM = 10, SC_GDOT_CAM = 11, SC_GMAX_CAM = 12,  // replicated
     SC_LIN_ITERS = 13, SC_LIN_RESID = 14, SC_LIN_STATUS = 15,
-    SC_COUNT = 16
+    SC_SCHUR_STATUS = 16,                             // rank-local; spread through the candidate cost (launch_status_poison);
+                                                      // next to the solver's slots: one memset clears all four per iteration
+    SC_COUNT = 17
 };
 
 struct Tile {      // one workgroup of ba_linearize / ba_cost
@@ -114,7 +116,8 @@ void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts
 void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, const uint32_t* blk_ptr, const uint32_t* blk_off,
                          const uint32_t* cam_ptr, const uint32_t* cam_off, const uint32_t* blk_row, const uint32_t* blk_col,
                          const uint32_t* free_cam /* camera of each free index */, const double* campre, const double* slab,
-                         const double* B, const double* gc, double* S, double* rhs, double* diagB, double* gc_red);
+                         const double* B, const double* gc, double* S, double* rhs, double* diagB, double* gc_red,
+                         const double* cost_in, double* cost_out /* cost_out = cost_in: this rank's cost joins the reduce payload */);
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,
                      LmDiag lm, const int32_t* diag_block, double* S, double* lc);

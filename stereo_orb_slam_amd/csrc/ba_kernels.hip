@@ -737,11 +737,13 @@ __global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, 
                                                              const double* __restrict__ campre, const double* __restrict__ slab,
                                                              const double* __restrict__ B, const double* __restrict__ gc,
                                                              double* __restrict__ S, double* __restrict__ rhs,
-                                                             double* __restrict__ diagB, double* __restrict__ gc_red)
+                                                             double* __restrict__ diagB, double* __restrict__ gc_red,
+                                                             const double* __restrict__ cost_in, double* __restrict__ cost_out)
 {
     __shared__ double t0[36], t1[36];
     const uint32_t id = blockIdx.x;
     const int t = threadIdx.x;
+    if (id == 0 && t == 0) *cost_out = *cost_in;   // this rank's cost joins the reduce payload (saves a 4-us copy command)
     if (id < n_blocks) {
         const uint32_t fa = blk_row[id], fb = blk_col[id];
         const int r = t / 6, c = t % 6;
@@ -1065,11 +1067,14 @@ void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts
 void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, const uint32_t* blk_ptr, const uint32_t* blk_off,
                          const uint32_t* cam_ptr, const uint32_t* cam_off, const uint32_t* blk_row, const uint32_t* blk_col,
                          const uint32_t* free_cam, const double* campre, const double* slab, const double* B, const double* gc,
-                         double* S, double* rhs, double* diagB, double* gc_red)
+                         double* S, double* rhs, double* diagB, double* gc_red, const double* cost_in, double* cost_out)
 {
-    if (!(n_blocks + n_free)) return;
+    if (!(n_blocks + n_free)) {
+        (void)hipMemcpyAsync(cost_out, cost_in, sizeof(double), hipMemcpyDeviceToDevice, s);
+        return;
+    }
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(n_blocks + n_free), dim3(64), 0, s, n_blocks, n_free, blk_ptr, blk_off, cam_ptr,
-                       cam_off, blk_row, blk_col, free_cam, campre, slab, B, gc, S, rhs, diagB, gc_red);
+                       cam_off, blk_row, blk_col, free_cam, campre, slab, B, gc, S, rhs, diagB, gc_red, cost_in, cost_out);
 }
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,

@@ -91,6 +91,7 @@ struct soslam_ba {
     uint32_t n_long = 0, n_long_pairs = 0, n_short = 0;
     std::vector<uint32_t> h_obs_cam, h_obs_pt;   // camera / internal point of each internal observation (debug read-back)
     DevBuf<uint32_t> row_ptr, ent_col, ent_blk, blk_row, blk_col;
+    DevBuf<int32_t> cr_map;             // gather map of the cyclic-reduction assembly (crsolve.hip)
 
     // state and work buffers
     DevBuf<double> cams[2], pts[2];
@@ -101,7 +102,8 @@ struct soslam_ba {
     double* reduce = nullptr;           // [S blocks | rhs | diagB | gc_red | tail(4)] [scalars(SC_COUNT)]
     uint64_t reduce_main = 0;           // f64 in the per-iteration system payload
     uint64_t reduce_count = 0;          // reduce_main + SC_COUNT: everything an all-reduce may touch
-    double* host_scal = nullptr;        // pinned, SC_COUNT + 4
+    double* host_raw = nullptr;         // pinned, 4 + SC_COUNT: the tail and the scalars as they lie in the reduce buffer
+    double* host_scal = nullptr;        // host_raw + 4
 
     // multi-GPU
     soslam_allreduce_fn allreduce = nullptr;
@@ -130,7 +132,7 @@ struct soslam_ba {
     ~soslam_ba()
     {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
-        if (host_scal) (void)hipHostFree(host_scal);
+        if (host_raw) (void)hipHostFree(host_raw);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -623,6 +625,9 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                 std::getenv("SOSLAM_NO_CR") == nullptr;
     if (h->use_cr) {
         SOSLAM_CHECK(h->cr_ws.alloc(cr_count(nf, h->bw)));
+        std::vector<int32_t> map(cr_map_count(nf, h->bw));
+        cr_build_map(nf, h->bw, h->n_blocks, h->h_blk_row.data(), h->h_blk_col.data(), map.data());
+        SOSLAM_CHECK(h->cr_map.upload(map, s));
         h->band.release(); h->bandT.release(); h->band_dinv.release();
     } else if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) {
         h->cr_ws.release();
@@ -640,7 +645,10 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->reduce_own.alloc(h->reduce_count));
     SOSLAM_CHECK(h->reduce_own.zero(s));
     h->reduce = h->reduce_own.p;
-    if (!h->host_scal) SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_scal), sizeof(double) * (SC_COUNT + 4), hipHostMallocDefault));
+    if (!h->host_raw) {
+        SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_raw), sizeof(double) * (SC_COUNT + 4), hipHostMallocDefault));
+        h->host_scal = h->host_raw + 4;
+    }
     SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
     h->have_problem = true;
     h->have_state = false;
@@ -711,8 +719,7 @@ int take_step(soslam_ba* h, double radius)
         run_schur(h, lm);
         launch_schur_reduce(s, h->n_blocks, h->n_free, h->blk_contrib_ptr.p, h->blk_contrib_off.p, h->cam_contrib_ptr.p,
                             h->cam_contrib_off.p, h->blk_row.p, h->blk_col.p, h->free_cam.p, h->campre.p, h->slab.p, h->B.p, h->gc.p,
-                            h->S(), h->rhs(), h->diagB(), h->gc_red());
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->tail(), h->scalp() + SC_COST_X, sizeof(double), hipMemcpyDeviceToDevice, s));
+                            h->S(), h->rhs(), h->diagB(), h->gc_red(), h->scalp() + SC_COST_X, h->tail());
     }
     {
         StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
@@ -733,10 +740,10 @@ int take_step(soslam_ba* h, double radius)
                     launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
                 }
             } else if (h->use_cr && h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
-                launch_cr_factor(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->cr_ws.p, h->scalp());
+                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp());
                 launch_cr_solve(s, h->n_free, h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, nullptr);
             } else if (h->use_cr && h->pcg_band) {
-                launch_cr_factor(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->cr_ws.p, h->scalp());
+                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp());
                 launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
                               h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, h->cr_rounds), h->scalp());
                 resid = h->lin_resid.p;
@@ -793,8 +800,8 @@ int take_step(soslam_ba* h, double radius)
     }
     {
         StageScope sc(h, SOSLAM_STAGE_SYNC);
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_scal, h->scalp(), sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, s));
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_scal + SC_COUNT, h->tail(), sizeof(double), hipMemcpyDeviceToHost, s));
+        // the tail (this iteration's cost at the linearisation point, summed over ranks) lies right in front of the scalars
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_raw, h->tail(), sizeof(double) * (4 + SC_COUNT), hipMemcpyDeviceToHost, s));
         SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
     }
     SOSLAM_HIP_CHECK(hipGetLastError());
@@ -819,7 +826,7 @@ StepScalars read_scalars(const soslam_ba* h)
 {
     const double* v = h->host_scal;
     StepScalars r;
-    r.x_cost = v[SC_COUNT];
+    r.x_cost = h->host_raw[0];
     r.cand_cost = v[SC_CAND_COST];
     r.mcc = v[SC_MCC_PTS] + v[SC_MCC_CAM];
     r.step_norm = std::sqrt(v[SC_STEP2_PTS] + v[SC_STEP2_CAM]);
@@ -857,8 +864,8 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         if (it >= max_it) { sum.termination = SOSLAM_TERM_MAX_ITERATIONS; break; }
         if (check && h->radius < o.min_radius) { sum.termination = SOSLAM_TERM_MIN_RADIUS; break; }
         if (check && o.max_solver_time_seconds > 0.0 && now_sec() - t0 > o.max_solver_time_seconds) { sum.termination = SOSLAM_TERM_TIME; break; }
-        SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp() + SC_SCHUR_STATUS, 0, sizeof(double), s));
-        SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp() + SC_LIN_ITERS, 0, 3 * sizeof(double), s));
+        static_assert(SC_SCHUR_STATUS == SC_LIN_ITERS + 3, "status slots are contiguous");
+        SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp() + SC_LIN_ITERS, 0, 4 * sizeof(double), s));
         const double radius = h->radius;
         SOSLAM_CHECK(take_step(h, radius));
         const StepScalars sc = read_scalars(h);

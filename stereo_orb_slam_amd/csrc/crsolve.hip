@@ -91,43 +91,31 @@ struct CrView {
     double *D, *F, *E, *P, *Q, *PT, *QT;   // each [m][sb*sb], row-major; P, Q (and transposes) indexed by the eliminated node
 };
 
-// scatter the upper block-sparse S into D (diagonal super-blocks) and F (F_i = A(i, i-1)); pad with identity
-__global__ __launch_bounds__(64) void cr_assemble_kernel(const double* __restrict__ blocks, const uint32_t* __restrict__ blk_row,
-                                                         const uint32_t* __restrict__ blk_col, uint32_t n_blocks,
-                                                         uint32_t n_rows, const CrView v)
+// gather the upper block-sparse S into D (diagonal super-blocks) and F (F_i = A(i, i-1)) through a host-built map
+// (cr_build_map): every element of both arrays is written - a 6x6 block of S, its transpose, zero, or the unit
+// diagonal of a padding camera - so no memset precedes it.  blockIdx = (super-block, 0: D / 1: F).
+__global__ __launch_bounds__(256) void cr_gather_kernel(const double* __restrict__ blocks, const int32_t* __restrict__ map, const CrView v)
 {
-    const int t = threadIdx.x;
-    const size_t sb2 = (size_t)v.sb * v.sb;
-    if (blockIdx.x < n_blocks) {
-        if (t >= 36) return;
-        const uint32_t ca = blk_row[blockIdx.x], cb = blk_col[blockIdx.x];   // ca <= cb
-        const uint32_t ia = ca / (uint32_t)v.bw, ib = cb / (uint32_t)v.bw;
-        const int la = (int)(ca - ia * v.bw), lb = (int)(cb - ib * v.bw);
-        const int r = t / 6, c = t % 6;
-        const double val = blocks[36 * (size_t)blockIdx.x + t];
-        if (ia == ib) {
-            v.D[ia * sb2 + (size_t)(la * 6 + r) * v.sb + lb * 6 + c] = val;
-            v.D[ia * sb2 + (size_t)(lb * 6 + c) * v.sb + la * 6 + r] = val;
+    const int sb = v.sb, bw = v.bw;
+    const uint32_t i = blockIdx.x;
+    const bool is_f = blockIdx.y != 0;
+    const size_t sb2 = (size_t)sb * sb;
+    double* dst = (is_f ? v.F : v.D) + i * sb2;
+    const int32_t* mp = map + ((size_t)(is_f ? v.m : 0) + i) * bw * bw;
+    for (int e = threadIdx.x; e < sb * sb; e += 256) {
+        const int r = e / sb, c = e - r * sb;
+        const int la = r / 6, rr = r - la * 6, lb = c / 6, cc = c - lb * 6;
+        double val = 0.0;
+        if (is_f) {
+            const int32_t id = mp[la * bw + lb];
+            if (id >= 0) val = blocks[36 * (size_t)id + cc * 6 + rr];
         } else {
-            v.F[ib * sb2 + (size_t)(lb * 6 + c) * v.sb + la * 6 + r] = val;
+            const int32_t id = la <= lb ? mp[la * bw + lb] : mp[lb * bw + la];
+            if (id >= 0) val = la <= lb ? blocks[36 * (size_t)id + rr * 6 + cc] : blocks[36 * (size_t)id + cc * 6 + rr];
+            else if (id == -2 && r == c) val = 1.0;
         }
-    } else {
-        // padding cameras of the last super-block: unit diagonal
-        const uint32_t cam = n_rows + (blockIdx.x - n_blocks);
-        if (t < 6 && cam < v.m * (uint32_t)v.bw) {
-            const uint32_t i = cam / (uint32_t)v.bw;
-            const int l = (int)(cam - i * v.bw) * 6 + t;
-            v.D[i * sb2 + (size_t)l * v.sb + l] = 1.0;
-        }
+        dst[e] = val;
     }
-}
-
-
-__device__ __forceinline__ double readlane_f64(double v, int src_lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
 }
 
 // Eliminated node i = h (2 j + 1)  (or node 0 when final != 0): E_i = D_i^-1 by a block Gauss-Jordan sweep.
@@ -557,15 +545,37 @@ size_t cr_count(uint32_t n_rows, int bw)
     return kCrMats * m * sb * sb + m * sb + 64;   // D F E P Q PT QT + padded work vector
 }
 
-void launch_cr_factor(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, int bw,
-                      double* ws, double* scal)
+size_t cr_map_count(uint32_t n_rows, int bw)
+{
+    const size_t m = (n_rows + (size_t)bw - 1) / (size_t)bw;
+    return 2 * m * bw * bw;
+}
+
+// map[(i bw + la) bw + lb], first m super-blocks for D (la <= lb used), then m for F: the block of S that fills the 6x6
+// block (camera la of super-block i, camera lb of super-block i resp. i - 1); -1: zero, -2: unit diagonal (padding)
+void cr_build_map(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, int32_t* map)
+{
+    const uint32_t m = (n_rows + (uint32_t)bw - 1) / (uint32_t)bw;
+    const size_t per = (size_t)m * bw * bw;
+    for (size_t e = 0; e < 2 * per; e++) map[e] = -1;
+    for (uint32_t cam = n_rows; cam < m * (uint32_t)bw; cam++) {
+        const uint32_t i = cam / (uint32_t)bw, l = cam - i * (uint32_t)bw;
+        map[((size_t)i * bw + l) * bw + l] = -2;
+    }
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const uint32_t ca = blk_row[b], cb = blk_col[b];   // ca <= cb
+        const uint32_t ia = ca / (uint32_t)bw, ib = cb / (uint32_t)bw;
+        const uint32_t la = ca - ia * (uint32_t)bw, lb = cb - ib * (uint32_t)bw;
+        if (ia == ib) map[((size_t)ia * bw + la) * bw + lb] = (int32_t)b;
+        else map[per + ((size_t)ib * bw + lb) * bw + la] = (int32_t)b;   // F_ib: row camera cb, column camera ca
+    }
+}
+
+void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal)
 {
     if (!A.n_rows) return;
     const CrView v = make_view(A.n_rows, bw, ws);
-    const size_t per = (size_t)v.m * v.sb * v.sb;
-    (void)hipMemsetAsync(v.D, 0, sizeof(double) * 2 * per, s);   // D and F
-    const uint32_t pad = v.m * (uint32_t)bw - A.n_rows;
-    hipLaunchKernelGGL(cr_assemble_kernel, dim3(n_blocks + pad), dim3(64), 0, s, A.blocks, blk_row, blk_col, n_blocks, A.n_rows, v);
+    hipLaunchKernelGGL(cr_gather_kernel, dim3(v.m, 2), dim3(256), 0, s, A.blocks, map, v);
     const size_t kp = ((size_t)v.sb + 3) & ~(size_t)3;
     const size_t lds_r = sizeof(double) * 4 * kp * kLd;
     if (lds_r > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);

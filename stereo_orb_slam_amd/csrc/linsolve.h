@@ -81,8 +81,9 @@ void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band
 // Usable for bw <= kCrBandMax; the sequential band kernels above remain the path for wider bands.
 constexpr int kCrBandMax = 10;
 size_t cr_count(uint32_t n_rows, int bw);   // f64 of workspace (D, F, Linv, U, V super-blocks + padded vector)
-void launch_cr_factor(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, int bw,
-                      double* ws, double* scal);
+size_t cr_map_count(uint32_t n_rows, int bw);   // int32 entries of the gather map
+void cr_build_map(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, int32_t* map);   // host
+void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal);
 // x = S^-1 b with the factors in ws; every launch returns at once when *done_flag != 0 (may be NULL)
 void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const double* b, double* x, const double* done_flag);
 // PCG rounds as launch_pcg_band, preconditioner = the cyclic-reduction factor
