@@ -6,15 +6,16 @@
 // the system per level: ceil(log2 m) levels of two kernels each (m = 56 super-blocks at BASELINE.json configs[2]).
 //
 // Level h, eliminated nodes i = h (2j+1), remaining nodes k = 2 h j, F_n = A(n, n-h) the coupling to the left:
-//   cr_invert : E_i = D_i^-1                       (block Gauss-Jordan sweep in LDS, 6x6 pivots, one workgroup per node)
+//   cr_invert : E_i = D_i^-1                       (block Gauss-Jordan sweep, 3x3 pivots, matrix in the accumulator registers
+//                                                   of the f64 matrix cores, one workgroup per node)
 //   cr_reduce : per remaining k with a = k-h, c = k+h (f64 matrix cores, one workgroup per 16 columns of the node)
 //                 Q_a = E_a F_k^T        P_c = E_c F_c
 //                 D_k -= F_k Q_a + F_c^T P_c        F_k <- -Q_a^T F_a      (fill: A(k, k-2h))
 // Each product is owned by exactly one remaining node.  With the explicit inverse every step of a later solve is a
 // matrix-vector product:   forward   w_k -= Q_a^T w_a + P_c^T w_c      backward   x_i = E_i w_i - P_i x_{i-h} - Q_i x_{i+h}
-// i.e. 2 ceil(log2 m) + 1 small launches without any dependent chain inside a launch.  All sums run in a fixed
+// i.e. 2 ceil(log2 m) - 1 small launches (the single-node top of the tree is one) without a dependent chain inside.  All sums run in a fixed
 // order: bitwise reproducible.  Positive definiteness is inherited by every Schur complement, so the sweep needs no
-// pivoting; a non-positive 6x6 pivot block raises scal[SC_LIN_STATUS].
+// pivoting; a non-positive 3x3 pivot block raises scal[SC_LIN_STATUS].
 #include "linsolve.h"
 
 #include "ba_kernels.h"
@@ -24,48 +25,6 @@ namespace soslam {
 namespace {
 
 constexpr int kCrReduceThreads = 256;
-
-__device__ __forceinline__ double rsqrt_nr(double s)
-{
-    double y = __builtin_amdgcn_rsq(s);
-    y = y * (1.5 - 0.5 * s * y * y);
-    y = y * (1.5 - 0.5 * s * y * y);
-    return y;
-}
-
-// lower Cholesky factor and its inverse of the 6x6 block at A (row stride lda), in registers
-__device__ __forceinline__ bool chol6_lds(const double* __restrict__ A, int lda, double (&L)[6][6], double (&Li)[6][6])
-{
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-#pragma unroll
-        for (int i = j; i < 6; i++) {
-            double s = A[i * lda + j];
-#pragma unroll
-            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
-            if (i == j) {
-                ok = ok && (s > 0.0);
-                const double y = rsqrt_nr(s);
-                Li[j][j] = y;
-                L[j][j] = s * y;
-            } else {
-                L[i][j] = s * Li[j][j];
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 6; j++)
-#pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = j; k < i; k++) s -= L[i][k] * Li[k][j];
-            Li[i][j] = s * Li[i][i];
-        }
-    return ok;
-}
-
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int kLd = 65;   // leading dimension of the zero-padded LDS images fed to the matrix cores (sb <= 60): odd, so that
