@@ -113,6 +113,7 @@ struct soslam_ba {
     // trust region
     double radius = 0.0, decrease_factor = 2.0, x_cost = 0.0;
     bool linearized = false, scale_init = false;
+    bool campre_current = false;        // campre already holds the pose table of cams[cur] (set on acceptance, used once by linearize)
     int invalid_run = 0;
     std::vector<soslam_ba_iteration> log;
 
@@ -665,7 +666,9 @@ int linearize(soslam_ba* h)
     hipStream_t s = h->stream;
     {
         StageScope sc(h, SOSLAM_STAGE_LINEARIZE);
-        launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);
+        // after an accepted step the candidate's pose table is already in place (swapped in by the LM loop)
+        if (!h->campre_current) launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);
+        h->campre_current = false;
         launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p,
                          h->proj, h->opt.huber_delta, h->ar.p, h->tile_part.p);
         launch_cam_reduce(s, h->n_cam, h->cam_tile_start.p, h->cam_free.p, h->tile_part.p, h->B.p, h->gc.p);
@@ -786,7 +789,8 @@ int take_step(soslam_ba* h, double radius)
     }
     {
         StageScope sc(h, SOSLAM_STAGE_COST);
-        // the candidate gets its own pose table: campre stays at the linearisation point, the compact rows need it
+        // the candidate gets its own pose table: campre stays at the linearisation point, the compact rows need it;
+        // an accepted step swaps the two tables instead of preparing the same poses again
         launch_pose_prepare(s, h->n_cam, h->cams[h->cur ^ 1].p, h->campre_c.p);
         launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->proj,
                     h->opt.huber_delta, h->cost_part.p);
@@ -921,6 +925,8 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         e.relative_decrease = rel;
         if (rel > o.min_relative_decrease) {
             h->cur ^= 1;
+            h->campre.swap(h->campre_c);   // the candidate's table becomes the linearisation point's
+            h->campre_current = true;
             h->x_cost = sc.cand_cost;
             SOSLAM_CHECK(linearize(h));
             double f = 1.0 - std::pow(2.0 * rel - 1.0, 3.0);

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "soslam_ba.h"
@@ -81,6 +82,12 @@ struct DevBuf {
     {
         if (n) SOSLAM_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));
         return SOSLAM_OK;
+    }
+    void swap(DevBuf& o)
+    {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(cap, o.cap);
     }
 };
 
