@@ -374,10 +374,11 @@ def test_block_jacobi_pcg_when_the_band_does_not_fit(gpu, oracle_lib, prob1):
 
 
 @pytest.mark.parametrize("solver", [2, 3])
-@pytest.mark.parametrize("track", [3, 12, 16])
+@pytest.mark.parametrize("track", [3, 5, 8, 11, 12, 16])
 def test_band_solver_widths(gpu, oracle_lib, solver, track):
-    """Block half-bandwidths 2, 11 and 15 (the widest the LDS window admits) through the band factorisation
-    and both triangular-solve variants (one / two update items per lane)."""
+    """Block half-bandwidths 2, 4, 7, 10 (cyclic reduction: every instantiated step count of the register-resident
+    inverse, 11 / 7 / 5 / 22 super-blocks), 11 and 15 (sequential band kernels, the widest the LDS window admits,
+    both triangular-solve variants)."""
     ba, synth, L = gpu
     p = synth.generate_ba(None, n_cam=45, n_pt=1800, track_mode=0, track_len=track, spacing=0.4)
     ref = oracle_lib.step(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, 1e4)
