@@ -80,7 +80,7 @@ void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band
 // ---- block cyclic reduction (crsolve.hip): the same band, factored level by level over many workgroups ---------
 // Usable for bw <= kCrBandMax; the sequential band kernels above remain the path for wider bands.
 constexpr int kCrBandMax = 10;
-size_t cr_count(uint32_t n_rows, int bw);   // f64 of workspace (D, F, Linv, U, V super-blocks + padded vector)
+size_t cr_count(uint32_t n_rows, int bw);   // f64 of workspace (D, F, E, P, Q, P^T, Q^T super-blocks + padded vector)
 size_t cr_map_count(uint32_t n_rows, int bw);   // int32 entries of the gather map
 void cr_build_map(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, int32_t* map);   // host
 void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal);
