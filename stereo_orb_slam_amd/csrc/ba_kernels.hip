@@ -230,8 +230,26 @@ __global__ __launch_bounds__(kTileThreads) void ba_cost_kernel(
 }
 
 // fixed-order sum of a strided column: one workgroup, each lane a fixed subsequence, then a fixed tree
+struct Publish {   // optional tail of a one-workgroup kernel: n <= 64 doubles to pinned host memory, then a sequence number
+    const double* src;
+    double* host_dst;
+    unsigned long long* host_seq;
+    unsigned long long seq;
+    int n;
+};
+
+__device__ __forceinline__ void publish_tail(const Publish& pb)
+{
+    if (!pb.host_dst) return;   // uniform
+    __syncthreads();            // the kernel's own result is among the published values
+    if ((int)threadIdx.x < pb.n) pb.host_dst[threadIdx.x] = pb.src[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __atomic_store_n(pb.host_seq, pb.seq, __ATOMIC_RELEASE);
+}
+
 __global__ __launch_bounds__(1024) void sum_strided_kernel(const double* __restrict__ in, uint32_t n, uint32_t stride,
-                                                            uint32_t offset, double scale, double* __restrict__ out)
+                                                            uint32_t offset, double scale, double* __restrict__ out, const Publish pb)
 {
     __shared__ double red[16];
     double s = 0.0;
@@ -244,6 +262,7 @@ __global__ __launch_bounds__(1024) void sum_strided_kernel(const double* __restr
         for (int w = 0; w < 16; w++) t += red[w];
         out[0] = scale * t;
     }
+    publish_tail(pb);
 }
 
 __global__ __launch_bounds__(1024) void sum5_kernel(const double* __restrict__ in, uint32_t n, double* __restrict__ out)
@@ -996,7 +1015,26 @@ void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float
 
 void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out)
 {
-    hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, in, n, stride, offset, scale, out);
+    hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, in, n, stride, offset, scale, out, Publish{nullptr, nullptr, nullptr, 0ull, 0});
+}
+
+// The scalars the host decides on, written straight into pinned host memory, then a sequence number: the host
+// polls that word instead of waiting for a copy command and its completion signal.
+// The scalars the host decides on go straight into pinned host memory, followed by a sequence number: the host polls
+// that word instead of waiting for a copy command and its completion signal.  Normally the tail of the iteration's
+// last kernel (the candidate-cost sum); a kernel of its own when a collective comes after that sum.
+__global__ __launch_bounds__(64) void ba_publish_kernel(const Publish pb) { publish_tail(pb); }
+
+void launch_publish(hipStream_t s, const double* src, int n, double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+{
+    hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, s, Publish{src, host_dst, host_seq, seq, n});
+}
+
+void launch_sum_strided_publish(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out,
+                                const double* src, int n_pub, double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+{
+    hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, in, n, stride, offset, scale, out,
+                       Publish{src, host_dst, host_seq, seq, n_pub});
 }
 
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out)

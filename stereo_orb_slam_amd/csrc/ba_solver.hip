@@ -104,6 +104,8 @@ struct soslam_ba {
     uint64_t reduce_count = 0;          // reduce_main + SC_COUNT: everything an all-reduce may touch
     double* host_raw = nullptr;         // pinned, 4 + SC_COUNT: the tail and the scalars as they lie in the reduce buffer
     double* host_scal = nullptr;        // host_raw + 4
+    unsigned long long* host_seq = nullptr;   // behind host_raw: sequence number of the last publication
+    unsigned long long publish_seq = 0;
 
     // multi-GPU
     soslam_allreduce_fn allreduce = nullptr;
@@ -647,8 +649,10 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->reduce_own.zero(s));
     h->reduce = h->reduce_own.p;
     if (!h->host_raw) {
-        SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_raw), sizeof(double) * (SC_COUNT + 4), hipHostMallocDefault));
+        SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_raw), sizeof(double) * (SC_COUNT + 4 + 1), hipHostMallocDefault));
         h->host_scal = h->host_raw + 4;
+        h->host_seq = reinterpret_cast<unsigned long long*>(h->host_raw + 4 + SC_COUNT);
+        *h->host_seq = 0;
     }
     SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
     h->have_problem = true;
@@ -716,6 +720,7 @@ constexpr uint32_t kPcgMultiMinRows = 64;   // below this one workgroup does a w
 int take_step(soslam_ba* h, double radius)
 {
     hipStream_t s = h->stream;
+    unsigned long long published = 0;   // sequence number if the scalars were already handed to the host
     const LmDiag lm = lm_diag(h, radius);
     {
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
@@ -794,7 +799,14 @@ int take_step(soslam_ba* h, double radius)
         launch_pose_prepare(s, h->n_cam, h->cams[h->cur ^ 1].p, h->campre_c.p);
         launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->proj,
                     h->opt.huber_delta, h->cost_part.p);
-        launch_sum_strided(s, h->cost_part.p, h->n_tiles, 1, 0, 0.5, h->scalp() + SC_CAND_COST);
+        if (h->world > 1) {
+            launch_sum_strided(s, h->cost_part.p, h->n_tiles, 1, 0, 0.5, h->scalp() + SC_CAND_COST);
+        } else {
+            // single rank: nothing follows this sum, so it also hands the iteration's scalars to the host
+            published = ++h->publish_seq;
+            launch_sum_strided_publish(s, h->cost_part.p, h->n_tiles, 1, 0, 0.5, h->scalp() + SC_CAND_COST, h->tail(), 4 + SC_COUNT,
+                                       h->host_raw, h->host_seq, published);
+        }
     }
     {
         StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
@@ -805,8 +817,26 @@ int take_step(soslam_ba* h, double radius)
     {
         StageScope sc(h, SOSLAM_STAGE_SYNC);
         // the tail (this iteration's cost at the linearisation point, summed over ranks) lies right in front of the scalars
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_raw, h->tail(), sizeof(double) * (4 + SC_COUNT), hipMemcpyDeviceToHost, s));
-        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        // a kernel writes them into pinned host memory and then a sequence number the host polls: no copy command,
+        // no completion signal between the GPU's last store and the host's decision
+        static_assert(4 + SC_COUNT <= 64, "one wave publishes the scalars");
+        unsigned long long seq = published;
+        if (!seq) {
+            seq = ++h->publish_seq;
+            launch_publish(s, h->tail(), 4 + SC_COUNT, h->host_raw, h->host_seq, seq);
+        }
+        SOSLAM_HIP_CHECK(hipGetLastError());
+        uint64_t spins = 0;
+        while (__atomic_load_n(h->host_seq, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0xFFFF) == 0) {   // a failed launch or a dead device must not spin forever
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipErrorNotReady && q != hipSuccess) SOSLAM_HIP_CHECK(q);
+                if (q == hipSuccess && __atomic_load_n(h->host_seq, __ATOMIC_ACQUIRE) != seq) {
+                    set_last_error("scalar publication did not arrive");
+                    return SOSLAM_ERR_HIP;
+                }
+            }
+        }
     }
     SOSLAM_HIP_CHECK(hipGetLastError());
     // The band factor is exact, so one PCG round (= a direct solve plus the true residual) normally meets the
