@@ -83,11 +83,14 @@ void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float
 // out[0] = scale * sum_{i<n} in[i*stride + offset], one workgroup, fixed order (bitwise reproducible)
 void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out);
 // per-workgroup partials [n][5] = {sum, sum, sum, sum, max} -> out[0..4]
-// n <= 64 doubles to pinned host memory, then *host_seq = seq (release at system scope)
-void launch_publish(hipStream_t s, const double* src, int n, double* host_dst, unsigned long long* host_seq, unsigned long long seq);
+// n <= 64 doubles to pinned host memory, then *host_seq = seq (release at system scope); src[clear_first .. +clear_n) are
+// zeroed afterwards (the status words of the next iteration)
+void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq,
+                    unsigned long long seq);
 // launch_sum_strided with the publication as the kernel's tail
 void launch_sum_strided_publish(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out,
-                                const double* src, int n_pub, double* host_dst, unsigned long long* host_seq, unsigned long long seq);
+                                double* src, int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq,
+                                unsigned long long seq);
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,

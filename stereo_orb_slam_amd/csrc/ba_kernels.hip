@@ -230,19 +230,24 @@ __global__ __launch_bounds__(kTileThreads) void ba_cost_kernel(
 }
 
 // fixed-order sum of a strided column: one workgroup, each lane a fixed subsequence, then a fixed tree
-struct Publish {   // optional tail of a one-workgroup kernel: n <= 64 doubles to pinned host memory, then a sequence number
-    const double* src;
+struct Publish {   // optional tail of a one-workgroup kernel: n <= 64 doubles to pinned host memory, then a sequence number;
+                   // the slots [clear_first, clear_first + clear_n) of src (status words) are zeroed for the next iteration
+    double* src;
     double* host_dst;
     unsigned long long* host_seq;
     unsigned long long seq;
-    int n;
+    int n, clear_first, clear_n;
 };
 
 __device__ __forceinline__ void publish_tail(const Publish& pb)
 {
     if (!pb.host_dst) return;   // uniform
     __syncthreads();            // the kernel's own result is among the published values
-    if ((int)threadIdx.x < pb.n) pb.host_dst[threadIdx.x] = pb.src[threadIdx.x];
+    const int t = threadIdx.x;
+    if (t < pb.n) {
+        pb.host_dst[t] = pb.src[t];
+        if (t >= pb.clear_first && t < pb.clear_first + pb.clear_n) pb.src[t] = 0.0;
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __atomic_store_n(pb.host_seq, pb.seq, __ATOMIC_RELEASE);
@@ -1015,7 +1020,7 @@ void launch_cost(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float
 
 void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out)
 {
-    hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, in, n, stride, offset, scale, out, Publish{nullptr, nullptr, nullptr, 0ull, 0});
+    hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, in, n, stride, offset, scale, out, Publish{nullptr, nullptr, nullptr, 0ull, 0, 0, 0});
 }
 
 // The scalars the host decides on, written straight into pinned host memory, then a sequence number: the host
@@ -1025,16 +1030,18 @@ void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t st
 // last kernel (the candidate-cost sum); a kernel of its own when a collective comes after that sum.
 __global__ __launch_bounds__(64) void ba_publish_kernel(const Publish pb) { publish_tail(pb); }
 
-void launch_publish(hipStream_t s, const double* src, int n, double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq,
+                    unsigned long long seq)
 {
-    hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, s, Publish{src, host_dst, host_seq, seq, n});
+    hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, s, Publish{src, host_dst, host_seq, seq, n, clear_first, clear_n});
 }
 
 void launch_sum_strided_publish(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out,
-                                const double* src, int n_pub, double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+                                double* src, int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq,
+                                unsigned long long seq)
 {
     hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, in, n, stride, offset, scale, out,
-                       Publish{src, host_dst, host_seq, seq, n_pub});
+                       Publish{src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
 }
 
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out)

@@ -805,7 +805,7 @@ int take_step(soslam_ba* h, double radius)
             // single rank: nothing follows this sum, so it also hands the iteration's scalars to the host
             published = ++h->publish_seq;
             launch_sum_strided_publish(s, h->cost_part.p, h->n_tiles, 1, 0, 0.5, h->scalp() + SC_CAND_COST, h->tail(), 4 + SC_COUNT,
-                                       h->host_raw, h->host_seq, published);
+                                       4 + SC_LIN_ITERS, 4, h->host_raw, h->host_seq, published);
         }
     }
     {
@@ -823,7 +823,7 @@ int take_step(soslam_ba* h, double radius)
         unsigned long long seq = published;
         if (!seq) {
             seq = ++h->publish_seq;
-            launch_publish(s, h->tail(), 4 + SC_COUNT, h->host_raw, h->host_seq, seq);
+            launch_publish(s, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, h->host_raw, h->host_seq, seq);
         }
         SOSLAM_HIP_CHECK(hipGetLastError());
         uint64_t spins = 0;
@@ -892,14 +892,15 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
     hipStream_t s = h->stream;
 
     if (!h->linearized) SOSLAM_CHECK(linearize(h));
+    // the solver / elimination status words start clean; every iteration's publication clears them again
+    static_assert(SC_SCHUR_STATUS == SC_LIN_ITERS + 3, "status slots are contiguous");
+    SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp() + SC_LIN_ITERS, 0, 4 * sizeof(double), s));
     bool have_initial = false;
     int it = 0;
     while (true) {
         if (it >= max_it) { sum.termination = SOSLAM_TERM_MAX_ITERATIONS; break; }
         if (check && h->radius < o.min_radius) { sum.termination = SOSLAM_TERM_MIN_RADIUS; break; }
         if (check && o.max_solver_time_seconds > 0.0 && now_sec() - t0 > o.max_solver_time_seconds) { sum.termination = SOSLAM_TERM_TIME; break; }
-        static_assert(SC_SCHUR_STATUS == SC_LIN_ITERS + 3, "status slots are contiguous");
-        SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp() + SC_LIN_ITERS, 0, 4 * sizeof(double), s));
         const double radius = h->radius;
         SOSLAM_CHECK(take_step(h, radius));
         const StepScalars sc = read_scalars(h);
