@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void pcg_band_matvec_kernel(const BsrView A, c
                                                               double* __restrict__ part, const double* __restrict__ state)
 {
     __shared__ double red[4];
-    if (state[PS_DONE] != 0.0) return;
+    if (state && state[PS_DONE] != 0.0) return;   // state == nullptr: first round of a solve, nothing to check yet
     const uint32_t n = A.n_rows * 6;
     const uint32_t i = (blockIdx.x * 256 + threadIdx.x) / kMatvecLanes, sub = threadIdx.x % kMatvecLanes;
     double s = 0.0;
@@ -537,6 +537,57 @@ __global__ __launch_bounds__(1024) void pcg_band_update_kernel(uint32_t n, uint3
     }
 }
 
+// First PCG round of a solve with x0 = 0 (cyclic-reduction path): r = b, p = z, so there is no direction step, no
+// initialisation pass and no copy of b - this kernel does what pcg_band_init, pcg_direction and pcg_band_update would:
+// |b|^2, r.z, alpha = r.z / p.q, x = alpha z, r = b - alpha q, p = z, the state words, the convergence test.
+__global__ __launch_bounds__(1024) void pcg_first_update_kernel(uint32_t n, uint32_t n_part, const double* __restrict__ part,
+                                                                const double* __restrict__ b, const double* __restrict__ z,
+                                                                const double* __restrict__ q, double* __restrict__ x,
+                                                                double* __restrict__ r, double* __restrict__ p,
+                                                                double* __restrict__ state, const double tol, double* __restrict__ scal)
+{
+    __shared__ double red[16];
+    double pq = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_part; i += 1024) pq += part[i];
+    pq = block_sum(pq, red);
+    double bb = 0.0, rz = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const double bi = b[i];
+        bb += bi * bi;
+        rz += bi * z[i];
+    }
+    bb = block_sum(bb, red);
+    rz = block_sum(rz, red);
+    if (!(bb > 0.0) || !(pq > 0.0)) {
+        // zero right-hand side: x = 0 is the answer; p.q <= 0 with b != 0: the matrix is not positive definite
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) { x[i] = 0.0; r[i] = b[i]; p[i] = z[i]; }
+        if (threadIdx.x == 0) {
+            state[PS_RZ] = rz; state[PS_BB] = bb; state[PS_DONE] = 1.0; state[PS_ROUNDS] = bb > 0.0 ? 1.0 : 0.0; state[PS_PQ] = 0.0;
+            if (bb > 0.0) scal[SC_LIN_STATUS] = 2.0;
+            scal[SC_LIN_ITERS] = state[PS_ROUNDS];
+            scal[SC_LIN_RESID] = bb > 0.0 ? 1.0 : 0.0;
+        }
+        return;
+    }
+    const double alpha = rz / pq;
+    double rr = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const double zi = z[i];
+        x[i] = alpha * zi;
+        const double ri = b[i] - alpha * q[i];
+        r[i] = ri;
+        p[i] = zi;
+        rr += ri * ri;
+    }
+    rr = block_sum(rr, red);
+    if (threadIdx.x == 0) {
+        state[PS_RZ] = rz; state[PS_BB] = bb; state[PS_ROUNDS] = 1.0; state[PS_PQ] = 0.0;
+        state[PS_DONE] = (rr > tol * tol * bb) ? 0.0 : 1.0;
+        scal[SC_LIN_ITERS] = 1.0;
+        scal[SC_LIN_RESID] = sqrt(rr / bb);
+    }
+}
+
 }  // namespace
 
 size_t band_count(uint32_t n_rows, int bw) { return (size_t)n_rows * (bw + 1) * 36; }
@@ -591,15 +642,19 @@ void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band
 void launch_pcg_cr(hipStream_t s, const BsrView& A, int bw, double* cr_ws, const double* b, double* x, double* resid, double* work,
                    double tol, int max_rounds, double* scal)
 {
-    if (!A.n_rows) return;
+    if (!A.n_rows || max_rounds < 1) return;
     const uint32_t n = A.n_rows * 6, n_wg = pcg_band_matvec_blocks(n);
     double* p = work;
     double* z = work + n;
     double* q = work + 2 * (size_t)n;
     double* state = work + 3 * (size_t)n;
     double* part = state + PS_COUNT;
-    hipLaunchKernelGGL(pcg_band_init_kernel, dim3(1), dim3(1024), 0, s, n, b, x, resid, state);
-    for (int round = 0; round < max_rounds; round++) {
+    // round 0 (x0 = 0, r = b, p = z): three steps, none of which looks at the state of the previous solve
+    launch_cr_solve(s, A.n_rows, bw, cr_ws, b, z, nullptr);
+    hipLaunchKernelGGL(pcg_band_matvec_kernel, dim3(n_wg), dim3(256), 0, s, A, z, q, part, nullptr);
+    hipLaunchKernelGGL(pcg_first_update_kernel, dim3(1), dim3(1024), 0, s, n, n_wg, part, b, z, q, x, resid, p, state, tol, scal);
+    for (int round = 1; round < max_rounds; round++) {
+        // every kernel of a later round returns at once when the previous round converged (device-side flag)
         launch_cr_solve(s, A.n_rows, bw, cr_ws, resid, z, state + PS_DONE);
         hipLaunchKernelGGL(pcg_direction_kernel, dim3(1), dim3(1024), 0, s, n, resid, z, p, state);
         hipLaunchKernelGGL(pcg_band_matvec_kernel, dim3(n_wg), dim3(256), 0, s, A, p, q, part, state);
