@@ -65,6 +65,25 @@ struct LmDiag {     // what a kernel needs to rebuild the point damping
     double radius, lo, hi;
 };
 
+// Ceres' damping of one diagonal entry in the Jacobi-scaled problem, expressed in unscaled units
+__device__ __forceinline__ double point_lambda(double cdiag, double s, const LmDiag& lm)
+{
+    const double s2 = s * s;
+    return fmin(fmax(s2 * cdiag, lm.lo), lm.hi) / (lm.radius * s2);
+}
+
+// Camera damping as ba_cam_damp_kernel applies it, for a caller that folds it into a kernel of its own (the cyclic
+// reduction's gather): lam = point_lambda(diag B, scale), lc = lam, diagonal of S += lam; scale set on the first pass.
+struct CamDamp {
+    const double* diagB;
+    double* sc;
+    double* lc;
+    const int32_t* diag_block;
+    LmDiag lm;
+    int init_scale, jacobi;
+    uint32_t n_free;
+};
+
 // campre[n_cam][kPoseStride]: per-camera rotation block consumed by launch_linearize / launch_cost
 void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, double* campre);
 

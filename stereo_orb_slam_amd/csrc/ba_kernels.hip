@@ -32,12 +32,6 @@ __device__ __forceinline__ double wave_max(double x)
     return x;
 }
 
-__device__ __forceinline__ double point_lambda(double cdiag, double s, const LmDiag& lm)
-{
-    const double s2 = s * s;
-    return fmin(fmax(s2 * cdiag, lm.lo), lm.hi) / (lm.radius * s2);
-}
-
 // per-camera rotation block (R, R*Jr, t, branch flag) - 24 f64 per camera, recomputed whenever poses change
 __global__ __launch_bounds__(64) void ba_pose_prepare_kernel(uint32_t n_cam, const double* __restrict__ cams,
                                                              double* __restrict__ campre)

@@ -735,8 +735,13 @@ int take_step(soslam_ba* h, double radius)
     }
     {
         StageScope sc(h, SOSLAM_STAGE_SOLVE);
-        launch_cam_damp(s, h->n_free, h->diagB(), h->sc.p, h->scale_init ? 0 : 1, h->opt.jacobi_scaling, lm, h->diag_block.p,
-                        h->S(), h->lc.p);
+        // camera damping onto S: a kernel of its own, except on the cyclic-reduction path, whose gather applies it
+        const bool damp_in_gather = h->use_cr && h->n_free && (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) &&
+                                    h->solver != SOSLAM_SOLVER_DENSE_CHOLESKY;
+        const CamDamp damp{h->diagB(), h->sc.p, h->lc.p, h->diag_block.p, lm, h->scale_init ? 0 : 1, h->opt.jacobi_scaling, h->n_free};
+        if (!damp_in_gather)
+            launch_cam_damp(s, h->n_free, h->diagB(), h->sc.p, h->scale_init ? 0 : 1, h->opt.jacobi_scaling, lm, h->diag_block.p,
+                            h->S(), h->lc.p);
         h->scale_init = true;
         const double* resid = nullptr;
         if (h->n_free) {
@@ -748,10 +753,10 @@ int take_step(soslam_ba* h, double radius)
                     launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
                 }
             } else if (h->use_cr && h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
-                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp());
+                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp);
                 launch_cr_solve(s, h->n_free, h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, nullptr);
             } else if (h->use_cr && h->pcg_band) {
-                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp());
+                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp);
                 launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
                               h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, h->cr_rounds), h->scalp());
                 resid = h->lin_resid.p;

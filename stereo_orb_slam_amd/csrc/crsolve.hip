@@ -53,11 +53,30 @@ struct CrView {
 // gather the upper block-sparse S into D (diagonal super-blocks) and F (F_i = A(i, i-1)) through a host-built map
 // (cr_build_map): every element of both arrays is written - a 6x6 block of S, its transpose, zero, or the unit
 // diagonal of a padding camera - so no memset precedes it.  blockIdx = (super-block, 0: D / 1: F).
-__global__ __launch_bounds__(256) void cr_gather_kernel(const double* __restrict__ blocks, const int32_t* __restrict__ map, const CrView v)
+__global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blocks, const int32_t* __restrict__ map, const CrView v,
+                                                        const CamDamp damp)
 {
     const int sb = v.sb, bw = v.bw;
     const uint32_t i = blockIdx.x;
     const bool is_f = blockIdx.y != 0;
+    if (damp.diagB && !is_f) {
+        // the LM damping of this super-block's cameras (what ba_cam_damp_kernel does for the other solvers): every
+        // diagonal block of S belongs to exactly one D workgroup, and no other workgroup reads it
+        const uint32_t u = i * (uint32_t)sb + threadIdx.x;
+        if ((int)threadIdx.x < sb && u < damp.n_free * 6) {
+            const uint32_t f = u / 6, a = u % 6;
+            const double d = damp.diagB[u];
+            double s = damp.sc[u];
+            if (damp.init_scale) {
+                s = damp.jacobi ? 1.0 / (1.0 + sqrt(d)) : 1.0;
+                damp.sc[u] = s;
+            }
+            const double lam = point_lambda(d, s, damp.lm);
+            damp.lc[u] = lam;
+            blocks[36 * (size_t)damp.diag_block[f] + a * 7] += lam;
+        }
+        __syncthreads();
+    }
     const size_t sb2 = (size_t)sb * sb;
     double* dst = (is_f ? v.F : v.D) + i * sb2;
     const int32_t* mp = map + ((size_t)(is_f ? v.m : 0) + i) * bw * bw;
@@ -530,11 +549,12 @@ void cr_build_map(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* bl
     }
 }
 
-void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal)
+void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp)
 {
     if (!A.n_rows) return;
     const CrView v = make_view(A.n_rows, bw, ws);
-    hipLaunchKernelGGL(cr_gather_kernel, dim3(v.m, 2), dim3(256), 0, s, A.blocks, map, v);
+    CamDamp none{};
+    hipLaunchKernelGGL(cr_gather_kernel, dim3(v.m, 2), dim3(256), 0, s, const_cast<double*>(A.blocks), map, v, damp ? *damp : none);
     const size_t kp = ((size_t)v.sb + 3) & ~(size_t)3;
     const size_t lds_r = sizeof(double) * 4 * kp * kLd;
     if (lds_r > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);

@@ -83,7 +83,9 @@ constexpr int kCrBandMax = 10;
 size_t cr_count(uint32_t n_rows, int bw);   // f64 of workspace (D, F, E, P, Q, P^T, Q^T super-blocks + padded vector)
 size_t cr_map_count(uint32_t n_rows, int bw);   // int32 entries of the gather map
 void cr_build_map(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, int32_t* map);   // host
-void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal);
+// damp != NULL: the gather also applies the camera damping to S in place (instead of a launch_cam_damp before it)
+struct CamDamp;
+void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp);
 // x = S^-1 b with the factors in ws; every launch returns at once when *done_flag != 0 (may be NULL)
 void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const double* b, double* x, const double* done_flag);
 // PCG rounds as launch_pcg_band, preconditioner = the cyclic-reduction factor
