@@ -106,10 +106,11 @@ void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t st
 // zeroed afterwards (the status words of the next iteration)
 void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq,
                     unsigned long long seq);
-// launch_sum_strided with the publication as the kernel's tail
-void launch_sum_strided_publish(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out,
-                                double* src, int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq,
-                                unsigned long long seq);
+// The iteration's two final sums in one launch: out5[0..4] = the five step scalars of the back-substitution partials
+// (sums, last one a max), out_cost = 0.5 sum cost_part; host_dst != NULL: then the publication (see launch_publish)
+void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cost_part, uint32_t n_cost,
+                      double* out_cost, double* pub_src, int n_pub, int clear_first, int clear_n, double* host_dst,
+                      unsigned long long* host_seq, unsigned long long seq);
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,

@@ -286,6 +286,38 @@ __global__ __launch_bounds__(1024) void sum5_kernel(const double* __restrict__ i
     }
 }
 
+// The two one-workgroup sums that end an iteration in one launch: the back-substitution's five step scalars (as
+// sum5_kernel) and the candidate cost (as sum_strided_kernel, stride 1, scale 0.5), then the optional publication.
+__global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __restrict__ part5, uint32_t n5, double* __restrict__ out5,
+                                                             const double* __restrict__ cost_part, uint32_t n_cost,
+                                                             double* __restrict__ out_cost, const Publish pb)
+{
+    __shared__ double red[16 * 6];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, mx = 0.0, sc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n5; i += 1024) {
+        const double* v = part5 + 5 * (size_t)i;
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        mx = fmax(mx, v[4]);
+    }
+    for (uint32_t i = threadIdx.x; i < n_cost; i += 1024) sc += cost_part[i];
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); mx = wave_max(mx); sc = wave_sum(sc);
+    if (threadIdx.x % kWave == 0) {
+        double* o = red + (threadIdx.x / kWave) * 6;
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = mx; o[5] = sc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0, e = 0.0, f = 0.0;
+        for (int w = 0; w < 16; w++) {
+            a += red[w * 6]; b += red[w * 6 + 1]; c += red[w * 6 + 2]; d += red[w * 6 + 3]; e = fmax(e, red[w * 6 + 4]);
+            f += red[w * 6 + 5];
+        }
+        out5[0] = a; out5[1] = b; out5[2] = c; out5[3] = d; out5[4] = e;
+        out_cost[0] = 0.5 * f;
+    }
+    publish_tail(pb);
+}
+
 // K3  camera blocks from the tile partials: one 64-lane workgroup per camera, lanes 0..26 each own one
 // value and add the camera's tiles in order (bitwise reproducible).
 __global__ __launch_bounds__(64) void ba_cam_reduce_kernel(const uint32_t* __restrict__ cam_tile_start,
@@ -1030,12 +1062,12 @@ void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clea
     hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, s, Publish{src, host_dst, host_seq, seq, n, clear_first, clear_n});
 }
 
-void launch_sum_strided_publish(hipStream_t s, const double* in, uint32_t n, uint32_t stride, uint32_t offset, double scale, double* out,
-                                double* src, int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq,
-                                unsigned long long seq)
+void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cost_part, uint32_t n_cost,
+                      double* out_cost, double* pub_src, int n_pub, int clear_first, int clear_n, double* host_dst,
+                      unsigned long long* host_seq, unsigned long long seq)
 {
-    hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, in, n, stride, offset, scale, out,
-                       Publish{src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
+    hipLaunchKernelGGL(ba_step_sums_kernel, dim3(1), dim3(1024), 0, s, part5, n5, out5, cost_part, n_cost, out_cost,
+                       Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
 }
 
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out)

@@ -795,7 +795,6 @@ int take_step(soslam_ba* h, double radius)
         launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->dcw.p, h->Cinv.p, h->C.p,
                        h->gp.p, h->sp.p, h->pts[h->cur].p, lm, h->opt.lower_bound, h->opt.upper_bound, h->pts[h->cur ^ 1].p,
                        h->dp.p, h->part.p);
-        launch_sum5(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS);
     }
     {
         StageScope sc(h, SOSLAM_STAGE_COST);
@@ -804,14 +803,12 @@ int take_step(soslam_ba* h, double radius)
         launch_pose_prepare(s, h->n_cam, h->cams[h->cur ^ 1].p, h->campre_c.p);
         launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->proj,
                     h->opt.huber_delta, h->cost_part.p);
-        if (h->world > 1) {
-            launch_sum_strided(s, h->cost_part.p, h->n_tiles, 1, 0, 0.5, h->scalp() + SC_CAND_COST);
-        } else {
-            // single rank: nothing follows this sum, so it also hands the iteration's scalars to the host
-            published = ++h->publish_seq;
-            launch_sum_strided_publish(s, h->cost_part.p, h->n_tiles, 1, 0, 0.5, h->scalp() + SC_CAND_COST, h->tail(), 4 + SC_COUNT,
-                                       4 + SC_LIN_ITERS, 4, h->host_raw, h->host_seq, published);
-        }
+        // one launch for the back-substitution's step scalars and the candidate cost; on a single rank nothing follows
+        // it, so it also hands the iteration's scalars to the host
+        if (h->world <= 1) published = ++h->publish_seq;
+        launch_step_sums(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS, h->cost_part.p, h->n_tiles,
+                         h->scalp() + SC_CAND_COST, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, published ? h->host_raw : nullptr,
+                         h->host_seq, published);
     }
     {
         StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
