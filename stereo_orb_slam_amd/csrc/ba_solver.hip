@@ -115,6 +115,7 @@ struct soslam_ba {
     // trust region
     double radius = 0.0, decrease_factor = 2.0, x_cost = 0.0;
     bool linearized = false, scale_init = false;
+    bool x_cost_known = false;          // x_cost is the cost at cams[cur], pts[cur] (accepted candidates: no sum over the tiles needed)
     bool campre_current = false;        // campre already holds the pose table of cams[cur] (set on acceptance, used once by linearize)
     int invalid_run = 0;
     std::vector<soslam_ba_iteration> log;
@@ -676,7 +677,9 @@ int linearize(soslam_ba* h)
         launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p,
                          h->proj, h->opt.huber_delta, h->ar.p, h->tile_part.p);
         launch_cam_reduce(s, h->n_cam, h->cam_tile_start.p, h->cam_free.p, h->tile_part.p, h->B.p, h->gc.p);
-        launch_sum_strided(s, h->tile_part.p, h->n_tiles, kTileVals, 27, 0.5, h->scalp() + SC_COST_X);
+        // the cost at this point: known on the host after an accepted step (it was the candidate's cost, summed over
+        // ranks); summed from the tiles only for a state the loop has not evaluated yet
+        if (!h->x_cost_known) launch_sum_strided(s, h->tile_part.p, h->n_tiles, kTileVals, 27, 0.5, h->scalp() + SC_COST_X);
     }
     {
         StageScope sc(h, SOSLAM_STAGE_POINT_REDUCE);
@@ -905,8 +908,10 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         if (check && o.max_solver_time_seconds > 0.0 && now_sec() - t0 > o.max_solver_time_seconds) { sum.termination = SOSLAM_TERM_TIME; break; }
         const double radius = h->radius;
         SOSLAM_CHECK(take_step(h, radius));
-        const StepScalars sc = read_scalars(h);
+        StepScalars sc = read_scalars(h);
+        if (h->x_cost_known) sc.x_cost = h->x_cost;   // the device slot is stale then (see linearize)
         h->x_cost = sc.x_cost;
+        h->x_cost_known = true;
         if (!have_initial) {
             have_initial = true;
             sum.initial_cost = sc.x_cost;
@@ -961,6 +966,7 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
             h->campre.swap(h->campre_c);   // the candidate's table becomes the linearisation point's
             h->campre_current = true;
             h->x_cost = sc.cand_cost;
+            h->x_cost_known = true;
             SOSLAM_CHECK(linearize(h));
             double f = 1.0 - std::pow(2.0 * rel - 1.0, 3.0);
             if (f < 1.0 / 3.0) f = 1.0 / 3.0;
@@ -983,9 +989,12 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
     sum.final_cost = h->x_cost;
     if (!have_initial) {
         // zero iterations requested: report the cost of the current point
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_scal, h->scalp(), sizeof(double), hipMemcpyDeviceToHost, s));
-        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
-        sum.initial_cost = sum.final_cost = h->x_cost = h->host_scal[0];
+        if (!h->x_cost_known) {
+            SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_scal, h->scalp(), sizeof(double), hipMemcpyDeviceToHost, s));
+            SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+            h->x_cost = h->host_scal[0];
+        }
+        sum.initial_cost = sum.final_cost = h->x_cost;
     }
     sum.solve_seconds = now_sec() - t0;
     collect_stage_times(h, &sum);
@@ -1091,7 +1100,7 @@ int soslam_ba_set_options(soslam_ba* h, const soslam_ba_options* opts)
     h->opt = *opts;
     h->opt.stream = stream;
     h->opt.device = device;
-    h->linearized = false;   // the linear solver was chosen (and its work space sized) in set_problem and stays
+    h->linearized = false; h->x_cost_known = false;   // the linear solver was chosen (and its work space sized) in set_problem and stays
     return SOSLAM_OK;
 }
 
@@ -1108,7 +1117,7 @@ int soslam_ba_set_projection(soslam_ba* h, const double* pl, const double* pr)
     std::memcpy(h->proj.l, pl, sizeof h->proj.l);
     std::memcpy(h->proj.r, pr, sizeof h->proj.r);
     h->have_proj = true;
-    h->linearized = false;
+    h->linearized = false; h->x_cost_known = false;
     return SOSLAM_OK;
 }
 
@@ -1118,7 +1127,7 @@ int soslam_ba_set_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t 
     if (!h || n_cam == 0 || (n_obs && (!obs_cam || !obs_pt || !obs_uv))) return SOSLAM_ERR_INVALID_ARGUMENT;
     SOSLAM_HIP_CHECK(hipSetDevice(h->device));
     h->have_problem = false;
-    h->linearized = false;
+    h->linearized = false; h->x_cost_known = false;
     return build_problem(h, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_uv, cam_fixed);
 }
 
@@ -1136,7 +1145,7 @@ int soslam_ba_set_state(soslam_ba* h, const double* poses, const double* points)
     h->radius = h->opt.initial_radius;
     h->decrease_factor = 2.0;
     h->invalid_run = 0;
-    h->linearized = false;
+    h->linearized = false; h->x_cost_known = false;
     h->scale_init = false;
     h->have_state = true;
     return SOSLAM_OK;
@@ -1213,12 +1222,12 @@ int soslam_ba_set_reduce_buffer(soslam_ba* h, void* ptr, uint64_t count)
 {
     if (!h) return SOSLAM_ERR_INVALID_ARGUMENT;
     if (!h->have_problem) { set_last_error("set_reduce_buffer before set_problem"); return SOSLAM_ERR_STATE; }
-    if (!ptr) { h->reduce = h->reduce_own.p; h->linearized = false; return SOSLAM_OK; }
+    if (!ptr) { h->reduce = h->reduce_own.p; h->linearized = false; h->x_cost_known = false; return SOSLAM_OK; }
     if (count < h->reduce_count) { set_last_error("reduce buffer too small: %llu < %llu f64", (unsigned long long)count, (unsigned long long)h->reduce_count); return SOSLAM_ERR_INVALID_ARGUMENT; }
     h->reduce = static_cast<double*>(ptr);
     SOSLAM_HIP_CHECK(hipMemsetAsync(h->reduce, 0, sizeof(double) * h->reduce_count, h->stream));
     SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
-    h->linearized = false;
+    h->linearized = false; h->x_cost_known = false;
     return SOSLAM_OK;
 }
 
@@ -1295,7 +1304,7 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
     (void)hipEventDestroy(e1);
     *avg_ms = ms / (float)reps;
     // the timed launches may have disturbed the reduce buffer / candidate; force a clean re-linearisation
-    h->linearized = false;
+    h->linearized = false; h->x_cost_known = false;
     SOSLAM_HIP_CHECK(hipGetLastError());
     return SOSLAM_OK;
 }
@@ -1306,6 +1315,7 @@ int soslam_ba_debug_step(soslam_ba* h, double radius)
     if (!h->have_problem || !h->have_state || !h->have_proj) { set_last_error("debug_step needs a problem and a state"); return SOSLAM_ERR_STATE; }
     SOSLAM_HIP_CHECK(hipSetDevice(h->device));
     h->scale_init = false;  // scaling from THIS linearisation, as on the first iteration
+    h->x_cost_known = false;   // the debug read-back reports the cost the device summed
     SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp(), 0, sizeof(double) * SC_COUNT, h->stream));
     SOSLAM_CHECK(linearize(h));
     SOSLAM_CHECK(take_step(h, radius));
