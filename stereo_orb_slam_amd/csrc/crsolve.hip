@@ -399,10 +399,11 @@ __global__ __launch_bounds__(kCrSolveThreads) void cr_fwd_kernel(const CrView v,
 }
 
 // backward, node i eliminated at stride h: x_i = E_i own_i - P_i x_{i-h} - Q_i x_{i+h}; own = the caller's right-hand side
-// at h = 1 (those nodes were never touched by the forward sweep), w otherwise.  The result goes to w (later levels
-// read it) and straight to the caller's x.
+// at h = 1 (those nodes were never touched by the forward sweep), w otherwise.  The result goes to the padded solution
+// vector xs (later levels read their neighbours there; w keeps the right-hand sides, which fused levels read again) and
+// straight to the caller's x.
 __global__ __launch_bounds__(kCrSolveThreads) void cr_bwd_kernel(const CrView v, const uint32_t h, const double* __restrict__ own,
-                                                                 const uint32_t n_own, double* __restrict__ w, double* __restrict__ x,
+                                                                 const uint32_t n_own, double* __restrict__ xs, double* __restrict__ x,
                                                                  const uint32_t n_x, const double* __restrict__ done_flag)
 {
     __shared__ double red[kCrSolveGroups][64];
@@ -416,13 +417,152 @@ __global__ __launch_bounds__(kCrSolveThreads) void cr_bwd_kernel(const CrView v,
     const uint32_t n_w = v.m * (uint32_t)sb;
     ColOp oe, oa, oc;
     col_load(oe, v.E + i * sb2, own, (size_t)i * sb, n_own, sb, t, g, true);   // E symmetric
-    col_load(oa, v.PT + i * sb2, w, (size_t)a * sb, n_w, sb, t, g, true);
-    col_load(oc, v.QT + i * sb2, w, (size_t)c * sb, n_w, sb, t, g, has_c);
+    col_load(oa, v.PT + i * sb2, xs, (size_t)a * sb, n_w, sb, t, g, true);
+    col_load(oc, v.QT + i * sb2, xs, (size_t)c * sb, n_w, sb, t, g, has_c);
     const double s = group_sum(col_dot(oe) - col_dot(oa) - col_dot(oc), red, t, g);
     if (g == 0 && t < sb) {
         const size_t ii = (size_t)i * sb + t;
-        w[ii] = s;
+        xs[ii] = s;
         if (ii < n_x) x[ii] = s;
+    }
+}
+
+// ---- two levels of a sweep in one launch --------------------------------------------------------------------------
+// A launch costs about as much as the memory round trip it contains, so two consecutive levels are fused by
+// recomputing what a workgroup needs from the lower level itself: the forward pair (h, 2h) has one workgroup per node
+// k = 4h j, which forms the level-h values of k - 2h, k and k + 2h (six products, three of them also formed by a
+// neighbour) and then its own level-2h value; the backward pair (2h, h) has one workgroup per level-h node, which first
+// solves its level-2h neighbour.  Every value is written by exactly one workgroup, and the arithmetic per node and its
+// order are those of cr_fwd_kernel / cr_bwd_kernel (the results are bitwise the same).
+struct MCol { double m[kCrSolveIters]; };
+
+__device__ __forceinline__ void mcol_load(MCol& o, const double* __restrict__ M, int sb, int t, int g, bool on)
+{
+#pragma unroll
+    for (int u = 0; u < kCrSolveIters; u++) {
+        const int m = g + u * kCrSolveGroups;
+        o.m[u] = (on && m < sb && t < sb) ? M[(size_t)m * sb + t] : 0.0;
+    }
+}
+
+// sum_m M[m][t] y[m], m = g, g + 8, ..; y: 64 doubles in LDS, zero from sb on
+__device__ __forceinline__ double mcol_dot(const MCol& o, const double* __restrict__ y, int g)
+{
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < kCrSolveIters; u++) {
+        const int m = g + u * kCrSolveGroups;
+        s += o.m[u] * (m < 64 ? y[m] : 0.0);
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(kCrSolveThreads) void cr_fwd2_kernel(const CrView v, const uint32_t h, const double* __restrict__ src,
+                                                                  const uint32_t n_src, double* __restrict__ w,
+                                                                  const double* __restrict__ done_flag)
+{
+    __shared__ double red[3][kCrSolveGroups][64];
+    __shared__ double yv[7][64];    // src of the nodes k - 3h .. k + 3h
+    __shared__ double w1[3][64];    // level-h values of k - 2h, k, k + 2h
+    if (cr_done(done_flag)) return;
+    const int sb = v.sb, t = threadIdx.x % 64, g = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    const size_t sb2 = (size_t)sb * sb;
+    const int64_t m = v.m, hh = h, k = 4 * hh * blockIdx.x;
+    if (k >= m) return;
+    const bool has[3] = {k >= 2 * hh, true, k + 2 * hh < m};
+    MCol qa[3], pc[3], q2, p2;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int64_t tn = k + (j - 1) * 2 * hh;
+        const bool ha = has[j] && tn >= hh, hc = has[j] && tn + hh < m;
+        mcol_load(qa[j], v.Q + (ha ? tn - hh : 0) * sb2, sb, t, g, ha);
+        mcol_load(pc[j], v.P + (hc ? tn + hh : 0) * sb2, sb, t, g, hc);
+    }
+    mcol_load(q2, v.Q + (has[0] ? k - 2 * hh : 0) * sb2, sb, t, g, has[0]);
+    mcol_load(p2, v.P + (has[2] ? k + 2 * hh : 0) * sb2, sb, t, g, has[2]);
+    if (g < 7) {
+        const int64_t node = k + (g - 3) * hh;
+        const size_t idx = (size_t)(node >= 0 ? node : 0) * sb + t;
+        yv[g][t] = (node >= 0 && node < m && t < sb && idx < n_src) ? src[idx] : 0.0;
+    }
+    __syncthreads();
+    // level h: node k + (j - 1) 2h reads its neighbours' vectors 2 j and 2 j + 2, its own is 2 j + 1
+#pragma unroll
+    for (int j = 0; j < 3; j++) red[j][g][t] = mcol_dot(qa[j], yv[2 * j], g) + mcol_dot(pc[j], yv[2 * j + 2], g);
+    __syncthreads();
+    if (g < 3) {
+        double s = red[g][0][t];
+#pragma unroll
+        for (int q = 1; q < kCrSolveGroups; q++) s += red[g][q][t];
+        const double val = has[g] ? yv[2 * g + 1][t] - s : 0.0;
+        w1[g][t] = t < sb ? val : 0.0;
+        if (g == 2 && has[2] && t < sb) w[(size_t)(k + 2 * hh) * sb + t] = val;   // final for the forward sweep
+    }
+    __syncthreads();
+    // level 2h: w_k = w'_k - Q^T w'_{k-2h} - P^T w'_{k+2h}
+    const double s = group_sum(mcol_dot(q2, w1[0], g) + mcol_dot(p2, w1[2], g), red[0], t, g);
+    if (g == 0 && t < sb) w[(size_t)k * sb + t] = w1[1][t] - s;
+}
+
+// levels 2h then h of the backward sweep; own_lo = the right-hand side the level-h nodes read (b at h = 1, else w)
+__global__ __launch_bounds__(kCrSolveThreads) void cr_bwd2_kernel(const CrView v, const uint32_t h, const double* __restrict__ own_lo,
+                                                                  const uint32_t n_own_lo, const double* __restrict__ w,
+                                                                  double* __restrict__ xs, double* __restrict__ x, const uint32_t n_x,
+                                                                  const double* __restrict__ done_flag)
+{
+    __shared__ double red[kCrSolveGroups][64];
+    __shared__ double yv[5][64];    // 0: w_i  1: x_{i-2h}  2: x_{i+2h}  3: own_j  4: x of j's other neighbour
+    __shared__ double xi[64];
+    if (cr_done(done_flag)) return;
+    const int sb = v.sb, t = threadIdx.x % 64, g = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    const size_t sb2 = (size_t)sb * sb;
+    const int64_t m = v.m, hh = h, j = hh * (2 * (int64_t)blockIdx.x + 1);
+    if (j >= m) return;
+    const int64_t lo = j - hh, hi = j + hh;
+    const bool i_is_lo = (lo % (4 * hh)) == 2 * hh;
+    const int64_t i = i_is_lo ? lo : hi, other = i_is_lo ? hi : lo;
+    const bool i_ok = i < m, other_ok = other < m;
+    const bool i_c = i_ok && i + 2 * hh < m;   // i - 2h >= 0 always
+    const uint32_t n_w = v.m * (uint32_t)sb;
+    MCol ei, pti, qti, ej, ptj, qtj;
+    mcol_load(ei, v.E + (i_ok ? i : 0) * sb2, sb, t, g, i_ok);
+    mcol_load(pti, v.PT + (i_ok ? i : 0) * sb2, sb, t, g, i_ok);
+    mcol_load(qti, v.QT + (i_ok ? i : 0) * sb2, sb, t, g, i_c);
+    mcol_load(ej, v.E + j * sb2, sb, t, g, true);
+    mcol_load(ptj, v.PT + j * sb2, sb, t, g, true);
+    mcol_load(qtj, v.QT + j * sb2, sb, t, g, hi < m);
+    if (g < 5) {
+        int64_t node; bool ok; const double* p = w; uint32_t lim = n_w;
+        if (g == 0) { node = i; ok = i_ok; }                                    // right-hand side of i: forward value
+        else if (g == 1) { node = i - 2 * hh; ok = i_ok; p = xs; }
+        else if (g == 2) { node = i + 2 * hh; ok = i_c; p = xs; }
+        else if (g == 3) { node = j; ok = true; p = own_lo; lim = n_own_lo; }
+        else { node = other; ok = other_ok; p = xs; }
+        const size_t idx = (size_t)(ok ? node : 0) * sb + t;
+        yv[g][t] = (ok && t < sb && idx < lim) ? p[idx] : 0.0;
+    }
+    __syncthreads();
+    // level 2h: x_i = E_i w_i - P_i x_{i-2h} - Q_i x_{i+2h}
+    {
+        const double s = group_sum(mcol_dot(ei, yv[0], g) - mcol_dot(pti, yv[1], g) - mcol_dot(qti, yv[2], g), red, t, g);
+        if (g == 0) {
+            xi[t] = (i_ok && t < sb) ? s : 0.0;
+            if (i_ok && !i_is_lo && t < sb) {   // i = j + h: this workgroup owns x_i
+                const size_t ii = (size_t)i * sb + t;
+                xs[ii] = s;
+                if (ii < n_x) x[ii] = s;
+            }
+        }
+        __syncthreads();
+    }
+    // level h: x_j = E_j own_j - P_j x_{j-h} - Q_j x_{j+h}
+    const double* xlo = i_is_lo ? xi : yv[4];
+    const double* xhi = i_is_lo ? yv[4] : xi;
+    const double s = group_sum(mcol_dot(ej, yv[3], g) - mcol_dot(ptj, xlo, g) - mcol_dot(qtj, xhi, g), red, t, g);
+    if (g == 0 && t < sb) {
+        const size_t jj = (size_t)j * sb + t;
+        xs[jj] = s;
+        if (jj < n_x) x[jj] = s;
     }
 }
 
@@ -431,7 +571,7 @@ __global__ __launch_bounds__(kCrSolveThreads) void cr_bwd_kernel(const CrView v,
 // workgroups.  All four operators are requested up front, the vectors travel through LDS.  Arithmetic and its order
 // are those of cr_fwd_kernel / cr_bwd_kernel.  m == 1: just x_0 = E_0 src_0.
 __global__ __launch_bounds__(kCrSolveThreads) void cr_top_kernel(const CrView v, const uint32_t h_top, const double* __restrict__ src,
-                                                                 const uint32_t n_src, double* __restrict__ w, double* __restrict__ x,
+                                                                 const uint32_t n_src, double* __restrict__ xs, double* __restrict__ x,
                                                                  const uint32_t n_x, const double* __restrict__ done_flag)
 {
     __shared__ double red[kCrSolveGroups][64];
@@ -476,7 +616,7 @@ __global__ __launch_bounds__(kCrSolveThreads) void cr_top_kernel(const CrView v,
         if (g == 0) {
             x0[t] = s;
             if (t < sb) {
-                w[t] = s;
+                xs[t] = s;
                 if ((uint32_t)t < n_x) x[t] = s;
             }
         }
@@ -494,7 +634,7 @@ __global__ __launch_bounds__(kCrSolveThreads) void cr_top_kernel(const CrView v,
         const double s = group_sum(de - da - 0.0, red, t, g);
         if (g == 0 && t < sb) {
             const size_t ic = (size_t)c * sb + t;
-            w[ic] = s;
+            xs[ic] = s;
             if (ic < n_x) x[ic] = s;
         }
     }
@@ -520,7 +660,7 @@ uint32_t count_even(uint32_t m, uint32_t h) { return (m + 2 * h - 1) / (2 * h); 
 size_t cr_count(uint32_t n_rows, int bw)
 {
     const size_t m = (n_rows + (size_t)bw - 1) / (size_t)bw, sb = 6 * (size_t)bw;
-    return kCrMats * m * sb * sb + m * sb + 64;   // D F E P Q PT QT + padded work vector
+    return kCrMats * m * sb * sb + 3 * m * sb + 64;   // D F E P Q PT QT + two padded right-hand-side buffers and the solution
 }
 
 size_t cr_map_count(uint32_t n_rows, int bw)
@@ -570,19 +710,46 @@ void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const d
 {
     if (!n_rows) return;
     const CrView v = make_view(n_rows, bw, ws);
-    double* w = ws + kCrMats * (size_t)v.m * v.sb * v.sb;
     const uint32_t n = n_rows * 6, n_pad = v.m * (uint32_t)v.sb;
+    // three padded vectors behind the matrices: two right-hand-side buffers (every forward launch reads one array and
+    // writes the other - with fused levels a node's old value is still being read elsewhere when its new one is stored)
+    // and the solution
+    double* buf[2] = {ws + kCrMats * (size_t)v.m * v.sb * v.sb, nullptr};
+    buf[1] = buf[0] + n_pad;
+    double* xs = buf[1] + n_pad;
     uint32_t h_top = 1;
     while (2 * h_top < v.m) h_top *= 2;           // largest power of two below m (1 for m <= 2)
-    // no copy in, no copy out: the first level that touches a node reads the caller's b, every backward kernel writes x
-    for (uint32_t h = 1; h < h_top; h *= 2)
-        hipLaunchKernelGGL(cr_fwd_kernel, dim3(count_even(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, h == 1 ? b : w, h == 1 ? n : n_pad, w,
+    // The right-hand side a node takes into the backward sweep is the value it had when its level was reached: own[l]
+    // for the nodes eliminated at stride 2^l.  No copy in, no copy out: the first level reads the caller's b, every
+    // backward kernel writes x.  Levels below the top go in pairs (cr_fwd2 / cr_bwd2), a left-over level alone.
+    struct Src { const double* p; uint32_t n; };
+    Src own[34];
+    Src cur{b, n};
+    int nb = 0, lev = 0;
+    uint32_t h = 1;
+    for (; 2 * h < h_top; h *= 4, lev += 2) {
+        double* out = buf[nb]; nb ^= 1;
+        own[lev] = cur;
+        hipLaunchKernelGGL(cr_fwd2_kernel, dim3((v.m + 4 * h - 1) / (4 * h)), dim3(kCrSolveThreads), 0, s, v, h, cur.p, cur.n, out, done_flag);
+        cur = Src{out, n_pad};
+        own[lev + 1] = cur;
+    }
+    const bool single = h < h_top;
+    if (single) {
+        double* out = buf[nb]; nb ^= 1;
+        own[lev] = cur;
+        hipLaunchKernelGGL(cr_fwd_kernel, dim3(count_even(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, cur.p, cur.n, out, done_flag);
+        cur = Src{out, n_pad};
+    }
+    hipLaunchKernelGGL(cr_top_kernel, dim3(1), dim3(kCrSolveThreads), 0, s, v, h_top, cur.p, cur.n, xs, x, n, done_flag);
+    if (single)
+        hipLaunchKernelGGL(cr_bwd_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, own[lev].p, own[lev].n, xs, x, n,
                            done_flag);
-    hipLaunchKernelGGL(cr_top_kernel, dim3(1), dim3(kCrSolveThreads), 0, s, v, h_top, h_top == 1 ? b : w, h_top == 1 ? n : n_pad, w, x, n,
-                       done_flag);
-    for (uint32_t h = h_top / 2; h >= 1; h /= 2)
-        hipLaunchKernelGGL(cr_bwd_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, h == 1 ? b : w, h == 1 ? n : n_pad, w, x,
-                           n, done_flag);
+    while (h > 1) {
+        h /= 4; lev -= 2;   // the pair (2h, h) = levels lev + 1, lev
+        hipLaunchKernelGGL(cr_bwd2_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, own[lev].p, own[lev].n,
+                           own[lev + 1].p, xs, x, n, done_flag);
+    }
 }
 
 }  // namespace soslam
