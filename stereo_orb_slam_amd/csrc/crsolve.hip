@@ -640,6 +640,98 @@ __global__ __launch_bounds__(kCrSolveThreads) void cr_top_kernel(const CrView v,
     }
 }
 
+// The top of the tree plus the level below it in one launch, for trees whose number of levels below the top is odd (the
+// pairs above leave one): nodes 0, q = h_top / 2, 2q = h_top, 3q.  Forward level q (nodes 0 and 2q), forward level 2q
+// (node 0), the root, backward level 2q (node 2q), backward level q (nodes q and 3q) - five dependent steps of one
+// workgroup, all twelve operators requested up front.  Arithmetic and order as in cr_fwd / cr_top / cr_bwd.
+__global__ __launch_bounds__(kCrSolveThreads) void cr_top2_kernel(const CrView v, const uint32_t q, const double* __restrict__ src,
+                                                                  const uint32_t n_src, double* __restrict__ xs, double* __restrict__ x,
+                                                                  const uint32_t n_x, const double* __restrict__ done_flag)
+{
+    __shared__ double red[2][kCrSolveGroups][64];
+    __shared__ double y[4][64];      // src of 0, q, 2q, 3q
+    __shared__ double w0a[64], w2a[64], w0b[64], x0[64], x2[64];
+    if (cr_done(done_flag)) return;
+    const int sb = v.sb, t = threadIdx.x % 64, g = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    const size_t sb2 = (size_t)sb * sb;
+    const uint32_t n1 = q, n2 = 2 * q, n3 = 3 * q;
+    const bool has3 = n3 < v.m;      // q and 2q exist (2q = h_top < m)
+    MCol pq, q1, p3, p2, e0, e2, pt2, e1, pt1, qt1, e3, pt3;
+    mcol_load(pq, v.P + n1 * sb2, sb, t, g, true);           // forward q, node 0:  c = q
+    mcol_load(q1, v.Q + n1 * sb2, sb, t, g, true);           // forward q, node 2q: a = q
+    mcol_load(p3, v.P + (has3 ? n3 : 0) * sb2, sb, t, g, has3);   //                c = 3q
+    mcol_load(p2, v.P + n2 * sb2, sb, t, g, true);           // forward 2q, node 0: c = 2q
+    mcol_load(e0, v.E, sb, t, g, true);
+    mcol_load(e2, v.E + n2 * sb2, sb, t, g, true);
+    mcol_load(pt2, v.PT + n2 * sb2, sb, t, g, true);
+    mcol_load(e1, v.E + n1 * sb2, sb, t, g, true);
+    mcol_load(pt1, v.PT + n1 * sb2, sb, t, g, true);
+    mcol_load(qt1, v.QT + n1 * sb2, sb, t, g, true);
+    mcol_load(e3, v.E + (has3 ? n3 : 0) * sb2, sb, t, g, has3);
+    mcol_load(pt3, v.PT + (has3 ? n3 : 0) * sb2, sb, t, g, has3);
+    if (g < 4) {
+        const uint32_t node = g * q;
+        const size_t idx = (size_t)node * sb + t;
+        y[g][t] = (node < v.m && t < sb && idx < n_src) ? src[idx] : 0.0;
+    }
+    __syncthreads();
+    // forward level q: w_0 -= P_q^T w_q;  w_2q -= Q_q^T w_q + P_3q^T w_3q
+    red[0][g][t] = 0.0 + mcol_dot(pq, y[1], g);
+    red[1][g][t] = mcol_dot(q1, y[1], g) + mcol_dot(p3, y[3], g);
+    __syncthreads();
+    if (g < 2) {
+        double s = red[g][0][t];
+#pragma unroll
+        for (int u = 1; u < kCrSolveGroups; u++) s += red[g][u][t];
+        if (g == 0) w0a[t] = t < sb ? y[0][t] - s : 0.0;
+        else w2a[t] = t < sb ? y[2][t] - s : 0.0;
+    }
+    __syncthreads();
+    // forward level 2q: w_0 -= P_2q^T w_2q
+    {
+        const double s = group_sum(0.0 + mcol_dot(p2, w2a, g), red[0], t, g);
+        if (g == 0) w0b[t] = t < sb ? w0a[t] - s : 0.0;
+        __syncthreads();
+    }
+    // root
+    {
+        const double s = group_sum(mcol_dot(e0, w0b, g) - 0.0 - 0.0, red[0], t, g);
+        if (g == 0) {
+            x0[t] = t < sb ? s : 0.0;
+            if (t < sb) {
+                xs[t] = s;
+                if ((uint32_t)t < n_x) x[t] = s;
+            }
+        }
+        __syncthreads();
+    }
+    // backward level 2q: x_2q = E w_2q - P x_0
+    {
+        const double s = group_sum(mcol_dot(e2, w2a, g) - mcol_dot(pt2, x0, g) - 0.0, red[0], t, g);
+        if (g == 0) {
+            x2[t] = t < sb ? s : 0.0;
+            if (t < sb) {
+                const size_t i2 = (size_t)n2 * sb + t;
+                xs[i2] = s;
+                if (i2 < n_x) x[i2] = s;
+            }
+        }
+        __syncthreads();
+    }
+    // backward level q: x_q = E w_q - P x_0 - Q x_2q;  x_3q = E w_3q - P x_2q
+    red[0][g][t] = mcol_dot(e1, y[1], g) - mcol_dot(pt1, x0, g) - mcol_dot(qt1, x2, g);
+    red[1][g][t] = mcol_dot(e3, y[3], g) - mcol_dot(pt3, x2, g) - 0.0;
+    __syncthreads();
+    if (g < 2 && t < sb && (g == 0 || has3)) {
+        double s = red[g][0][t];
+#pragma unroll
+        for (int u = 1; u < kCrSolveGroups; u++) s += red[g][u][t];
+        const size_t ii = (size_t)(g == 0 ? n1 : n3) * sb + t;
+        xs[ii] = s;
+        if (ii < n_x) x[ii] = s;
+    }
+}
+
 constexpr int kCrMats = 7;
 
 CrView make_view(uint32_t n_rows, int bw, double* ws)
@@ -734,17 +826,11 @@ void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const d
         cur = Src{out, n_pad};
         own[lev + 1] = cur;
     }
-    const bool single = h < h_top;
-    if (single) {
-        double* out = buf[nb]; nb ^= 1;
-        own[lev] = cur;
-        hipLaunchKernelGGL(cr_fwd_kernel, dim3(count_even(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, cur.p, cur.n, out, done_flag);
-        cur = Src{out, n_pad};
-    }
-    hipLaunchKernelGGL(cr_top_kernel, dim3(1), dim3(kCrSolveThreads), 0, s, v, h_top, cur.p, cur.n, xs, x, n, done_flag);
-    if (single)
-        hipLaunchKernelGGL(cr_bwd_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, own[lev].p, own[lev].n, xs, x, n,
-                           done_flag);
+    // an odd number of levels below the top leaves one: it joins the top (cr_top2)
+    if (h < h_top)
+        hipLaunchKernelGGL(cr_top2_kernel, dim3(1), dim3(kCrSolveThreads), 0, s, v, h, cur.p, cur.n, xs, x, n, done_flag);
+    else
+        hipLaunchKernelGGL(cr_top_kernel, dim3(1), dim3(kCrSolveThreads), 0, s, v, h_top, cur.p, cur.n, xs, x, n, done_flag);
     while (h > 1) {
         h /= 4; lev -= 2;   // the pair (2h, h) = levels lev + 1, lev
         hipLaunchKernelGGL(cr_bwd2_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, own[lev].p, own[lev].n,
