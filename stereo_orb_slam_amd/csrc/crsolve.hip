@@ -13,7 +13,8 @@
 //                 D_k -= F_k Q_a + F_c^T P_c        F_k <- -Q_a^T F_a      (fill: A(k, k-2h))
 // Each product is owned by exactly one remaining node.  With the explicit inverse every step of a later solve is a
 // matrix-vector product:   forward   w_k -= Q_a^T w_a + P_c^T w_c      backward   x_i = E_i w_i - P_i x_{i-h} - Q_i x_{i+h}
-// i.e. 2 ceil(log2 m) - 1 small launches (the single-node top of the tree is one) without a dependent chain inside.  All sums run in a fixed
+// i.e. one small launch per level and sweep - two levels per launch with cr_fwd2 / cr_bwd2 / cr_top2 (ceil(log2 m) - 1
+// launches per solve: 5 at m = 56).  All sums run in a fixed
 // order: bitwise reproducible.  Positive definiteness is inherited by every Schur complement, so the sweep needs no
 // pivoting; a non-positive 3x3 pivot block raises scal[SC_LIN_STATUS].
 #include "linsolve.h"
