@@ -1,10 +1,12 @@
 // pcg_multi.hip - multi-workgroup block-Jacobi PCG on a block-sparse symmetric matrix (6x6 blocks) + shift.
 //
-// Three kernels per iteration, each over ceil(n_rows / 42) workgroups of 256 lanes (42 block rows = 252 scalar
+// Two kernels per iteration, each over ceil(n_rows / 42) workgroups of 256 lanes (42 block rows = 252 scalar
 // rows per workgroup):
-//   matvec     q = (A + shift I) p, partial p.q
+//   matvec     convergence test and beta from the partials; p = z + beta p_old formed on the fly for every column the
+//              workgroup touches and stored for its own rows (p is double-buffered by iteration parity, the old one is
+//              still being read elsewhere); q = (A + shift I) p, partial p.q
 //   update     alpha from the partials; x += alpha p; r -= alpha q; z = M^-1 r; partial r.z and r.r
-//   direction  beta from the partials; p = z + beta p
+// (the direction step was a launch of its own; a dependent launch costs about 5 us here however little it does)
 // Partials are double-buffered by iteration parity; every workgroup sums them in the same fixed order, so all
 // agree bit for bit on alpha, beta and on convergence, and a converged solve turns the remaining launches of a
 // chunk into immediate returns.
@@ -25,7 +27,7 @@ constexpr int kThreads = 256;
 enum { ST_BB = 0, ST_ITERS = 1, ST_BREAKDOWN = 2, ST_DONE = 3, ST_COUNT = 4 };
 
 struct PcgBufs {
-    double *p, *z, *q, *minv, *part_pq, *part_rz, *part_rr, *state;   // part_rz / part_rr: [2][n_wg]
+    double *p[2], *z, *q, *minv, *part_pq, *part_rz, *part_rr, *state;   // p, part_rz, part_rr: by iteration parity
     uint32_t n_wg;
 };
 
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void pcgm_init_kernel(const BsrView A, co
         const double* rv = rloc + (t / 6) * 6;
         const double zi = M[0] * rv[0] + M[1] * rv[1] + M[2] * rv[2] + M[3] * rv[3] + M[4] * rv[4] + M[5] * rv[5];
         w.z[i] = zi;
-        w.p[i] = zi;
+        w.p[0][i] = zi;
         rz = bi * zi;
     }
     const double bb = block_sum256(bi * bi, red);
@@ -172,18 +174,62 @@ __device__ __forceinline__ bool converged(const PcgBufs& w, int parity, double t
     return !(rr > tol * tol * bb) || w.state[ST_BREAKDOWN] != 0.0;
 }
 
+// q_row of (A p) with p = z + beta p_old formed on the fly (FIRST: p is p_old itself, the init kernel's z)
+template <bool FIRST>
+__device__ __forceinline__ double bsr_row_dot_dir(const BsrView& A, uint32_t row, const double* __restrict__ z,
+                                                  const double* __restrict__ p_old, double beta)
+{
+    const uint32_t f = row / 6, a = row % 6;
+    double s = 0.0;
+    for (uint32_t e = A.row_ptr[f]; e < A.row_ptr[f + 1]; e++) {
+        const double* B = A.blocks + 36 * (size_t)A.ent_blk[e];
+        const size_t c0 = 6 * (size_t)A.ent_col[e];
+        double x[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) x[c] = FIRST ? p_old[c0 + c] : z[c0 + c] + beta * p_old[c0 + c];
+        if (A.ent_trans[e]) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) s += B[c * 6 + a] * x[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) s += B[a * 6 + c] * x[c];
+        }
+    }
+    return s;
+}
+
+// parity = iteration index & 1: the sums of the previous update (or of the init kernel) sit at `parity`, the ones before
+// at parity ^ 1; p of this iteration goes to w.p[parity], the previous one is w.p[parity ^ 1] (FIRST: w.p[0] is ready)
+template <bool FIRST>
 __global__ __launch_bounds__(kThreads) void pcgm_matvec_kernel(const BsrView A, const double shift, const PcgBufs w,
                                                                const int parity, const double tol)
 {
     __shared__ double red[4];
-    if (converged(w, parity, tol, red)) return;
+    if (w.state[ST_DONE] != 0.0) return;   // uniform: written by an earlier launch
+    {
+        // the previous update may have reached the tolerance: remember it (ST_DONE), or every second launch of the rest
+        // of the chunk would iterate on the stale sums of the other parity
+        const double rr = coop_sum(w.part_rr + parity * w.n_wg, w.n_wg, red);
+        if (!(rr > tol * tol * w.state[ST_BB]) || w.state[ST_BREAKDOWN] != 0.0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) w.state[ST_DONE] = 1.0;
+            return;
+        }
+    }
+    double beta = 0.0;
+    if (!FIRST) {
+        const double rz_new = coop_sum(w.part_rz + parity * w.n_wg, w.n_wg, red);
+        const double rz_old = coop_sum(w.part_rz + (parity ^ 1) * w.n_wg, w.n_wg, red);
+        beta = rz_new / rz_old;
+    }
+    const double* p_old = w.p[FIRST ? 0 : parity ^ 1];
     const uint32_t n = A.n_rows * 6;
     const int t = threadIdx.x;
     const uint32_t i = blockIdx.x * kRowsPerWg * 6 + t;
     double pq = 0.0;
     if (t < kRowsPerWg * 6 && i < n) {
-        const double pi = w.p[i];
-        const double qi = bsr_row_dot(A, i, w.p) + shift * pi;
+        const double pi = FIRST ? p_old[i] : w.z[i] + beta * p_old[i];
+        if (!FIRST) w.p[parity][i] = pi;
+        const double qi = bsr_row_dot_dir<FIRST>(A, i, w.z, p_old, beta) + shift * pi;
         w.q[i] = qi;
         pq = pi * qi;
     }
@@ -209,7 +255,7 @@ __global__ __launch_bounds__(kThreads) void pcgm_update_kernel(const uint32_t n,
     const bool act = t < kRowsPerWg * 6 && i < n;
     double ri = 0.0;
     if (act) {
-        x[i] += alpha * w.p[i];
+        x[i] += alpha * w.p[parity][i];
         ri = r[i] - alpha * w.q[i];
         r[i] = ri;
         rloc[t] = ri;
@@ -232,30 +278,12 @@ __global__ __launch_bounds__(kThreads) void pcgm_update_kernel(const uint32_t n,
     }
 }
 
-// parity = parity BEFORE the update kernel of this iteration; the new sums sit at parity ^ 1
-__global__ __launch_bounds__(kThreads) void pcgm_direction_kernel(const uint32_t n, const PcgBufs w, const int parity, const double tol)
-{
-    // the update kernel ran iff the system had not converged at `parity`; it may have converged now - p is then unused
-    __shared__ double red[4];
-    if (converged(w, parity, tol, red)) return;
-    if (converged(w, parity ^ 1, tol, red)) {   // this iteration's update reached the tolerance: remember it
-        if (blockIdx.x == 0 && threadIdx.x == 0) w.state[ST_DONE] = 1.0;
-        return;
-    }
-    const double rz_old = coop_sum(w.part_rz + parity * w.n_wg, w.n_wg, red);
-    const double rz_new = coop_sum(w.part_rz + (parity ^ 1) * w.n_wg, w.n_wg, red);
-    const double beta = rz_new / rz_old;
-    const int t = threadIdx.x;
-    const uint32_t i = blockIdx.x * kRowsPerWg * 6 + t;
-    if (t < kRowsPerWg * 6 && i < n) w.p[i] = w.z[i] + beta * w.p[i];
-}
-
 }  // namespace
 
 size_t pcg_multi_work_count(uint32_t n_rows)
 {
     const size_t n = (size_t)n_rows * 6, n_wg = (n_rows + kRowsPerWg - 1) / kRowsPerWg;
-    return 3 * n + 36 * (size_t)n_rows + 5 * n_wg + ST_COUNT + 16;
+    return 4 * n + 36 * (size_t)n_rows + 5 * n_wg + ST_COUNT + 16;
 }
 
 int pcg_multi_solve(hipStream_t s, const BsrView& A, double shift, const double* b, double* x, double* resid,
@@ -266,7 +294,7 @@ int pcg_multi_solve(hipStream_t s, const BsrView& A, double shift, const double*
     const uint32_t n = A.n_rows * 6, n_wg = (A.n_rows + kRowsPerWg - 1) / kRowsPerWg;
     PcgBufs w;
     w.n_wg = n_wg;
-    w.p = work; w.z = w.p + n; w.q = w.z + n; w.minv = w.q + n;
+    w.p[0] = work; w.p[1] = w.p[0] + n; w.z = w.p[1] + n; w.q = w.z + n; w.minv = w.q + n;
     w.part_pq = w.minv + 36 * (size_t)A.n_rows;
     w.part_rz = w.part_pq + n_wg;
     w.part_rr = w.part_rz + 2 * (size_t)n_wg;
@@ -282,9 +310,9 @@ int pcg_multi_solve(hipStream_t s, const BsrView& A, double shift, const double*
     while (launched < max_iter) {
         const int todo = std::min(chunk, max_iter - launched);
         for (int k = 0; k < todo; k++) {
-            hipLaunchKernelGGL(pcgm_matvec_kernel, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, parity, tol);
+            if (launched + k == 0) hipLaunchKernelGGL(pcgm_matvec_kernel<true>, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, parity, tol);
+            else hipLaunchKernelGGL(pcgm_matvec_kernel<false>, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, parity, tol);
             hipLaunchKernelGGL(pcgm_update_kernel, dim3(n_wg), dim3(kThreads), 0, s, n, x, r, w, parity, tol);
-            hipLaunchKernelGGL(pcgm_direction_kernel, dim3(n_wg), dim3(kThreads), 0, s, n, w, parity, tol);
             parity ^= 1;
         }
         launched += todo;
