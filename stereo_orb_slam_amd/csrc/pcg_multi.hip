@@ -163,15 +163,20 @@ __device__ __forceinline__ double coop_sum(const double* __restrict__ part, uint
     return block_sum256(v, red);
 }
 
-// The residual partials are double-buffered by iteration parity, so once the solve has converged the OTHER parity slot
-// still holds an unconverged sum: convergence has to be remembered (ST_DONE, set by the direction kernel of the
-// iteration that reached it), or every second launch of the rest of the chunk would iterate on stale data.
-__device__ __forceinline__ bool converged(const PcgBufs& w, int parity, double tol, double* red)
+// Three such sums at once: the loads of all three lists are in flight together and the workgroup synchronises twice
+// instead of six times.  The per-lane subsequences and the tree are those of coop_sum: same bits.
+__device__ __forceinline__ void coop_sum3(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c,
+                                          uint32_t n, double (*red3)[4], double& sa, double& sb, double& sc)
 {
-    if (w.state[ST_DONE] != 0.0) return true;   // uniform: written by an earlier launch
-    const double rr = coop_sum(w.part_rr + parity * w.n_wg, w.n_wg, red);
-    const double bb = w.state[ST_BB];
-    return !(rr > tol * tol * bb) || w.state[ST_BREAKDOWN] != 0.0;
+    double va = 0.0, vb = 0.0, vc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += kThreads) { va += a[i]; vb += b[i]; vc += c[i]; }
+    va = wave_sum(va); vb = wave_sum(vb); vc = wave_sum(vc);
+    __syncthreads();
+    if (threadIdx.x % 64 == 0) { red3[0][threadIdx.x / 64] = va; red3[1][threadIdx.x / 64] = vb; red3[2][threadIdx.x / 64] = vc; }
+    __syncthreads();
+    sa = red3[0][0] + red3[0][1] + red3[0][2] + red3[0][3];
+    sb = red3[1][0] + red3[1][1] + red3[1][2] + red3[1][3];
+    sc = red3[2][0] + red3[2][1] + red3[2][2] + red3[2][3];
 }
 
 // q_row of (A p) with p = z + beta p_old formed on the fly (FIRST: p is p_old itself, the init kernel's z)
@@ -205,22 +210,17 @@ __global__ __launch_bounds__(kThreads) void pcgm_matvec_kernel(const BsrView A, 
                                                                const int parity, const double tol)
 {
     __shared__ double red[4];
+    __shared__ double red3[3][4];
     if (w.state[ST_DONE] != 0.0) return;   // uniform: written by an earlier launch
-    {
-        // the previous update may have reached the tolerance: remember it (ST_DONE), or every second launch of the rest
-        // of the chunk would iterate on the stale sums of the other parity
-        const double rr = coop_sum(w.part_rr + parity * w.n_wg, w.n_wg, red);
-        if (!(rr > tol * tol * w.state[ST_BB]) || w.state[ST_BREAKDOWN] != 0.0) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) w.state[ST_DONE] = 1.0;
-            return;
-        }
+    double rr, rz_new, rz_old;
+    coop_sum3(w.part_rr + parity * w.n_wg, w.part_rz + parity * w.n_wg, w.part_rz + (parity ^ 1) * w.n_wg, w.n_wg, red3, rr, rz_new, rz_old);
+    // the previous update may have reached the tolerance: remember it (ST_DONE), or every second launch of the rest of
+    // the chunk would iterate on the stale sums of the other parity
+    if (!(rr > tol * tol * w.state[ST_BB]) || w.state[ST_BREAKDOWN] != 0.0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) w.state[ST_DONE] = 1.0;
+        return;
     }
-    double beta = 0.0;
-    if (!FIRST) {
-        const double rz_new = coop_sum(w.part_rz + parity * w.n_wg, w.n_wg, red);
-        const double rz_old = coop_sum(w.part_rz + (parity ^ 1) * w.n_wg, w.n_wg, red);
-        beta = rz_new / rz_old;
-    }
+    const double beta = FIRST ? 0.0 : rz_new / rz_old;
     const double* p_old = w.p[FIRST ? 0 : parity ^ 1];
     const uint32_t n = A.n_rows * 6;
     const int t = threadIdx.x;
@@ -241,10 +241,12 @@ __global__ __launch_bounds__(kThreads) void pcgm_update_kernel(const uint32_t n,
                                                                const PcgBufs w, const int parity, const double tol)
 {
     __shared__ double red[4];
+    __shared__ double red3[3][4];
     __shared__ double rloc[kRowsPerWg * 6];
-    if (converged(w, parity, tol, red)) return;
-    const double pq = coop_sum(w.part_pq, w.n_wg, red);
-    const double rz = coop_sum(w.part_rz + parity * w.n_wg, w.n_wg, red);
+    if (w.state[ST_DONE] != 0.0) return;   // uniform: written by an earlier launch
+    double rr_old, pq, rz;
+    coop_sum3(w.part_rr + parity * w.n_wg, w.part_pq, w.part_rz + parity * w.n_wg, w.n_wg, red3, rr_old, pq, rz);
+    if (!(rr_old > tol * tol * w.state[ST_BB]) || w.state[ST_BREAKDOWN] != 0.0) return;   // as the matvec of this iteration decided
     const int t = threadIdx.x;
     if (!(pq > 0.0)) {
         if (t == 0 && blockIdx.x == 0) w.state[ST_BREAKDOWN] = 2.0;
