@@ -81,9 +81,12 @@ __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blo
     const size_t sb2 = (size_t)sb * sb;
     double* dst = (is_f ? v.F : v.D) + i * sb2;
     const int32_t* mp = map + ((size_t)(is_f ? v.m : 0) + i) * bw * bw;
-    for (int e = threadIdx.x; e < sb * sb; e += 256) {
-        const int r = e / sb, c = e - r * sb;
-        const int la = r / 6, rr = r - la * 6, lb = c / 6, cc = c - lb * 6;
+    // lane = column, wave = every fourth row: divisions by the constant 6 only, coalesced stores, independent loads
+    const int c = threadIdx.x % 64, lb = c / 6, cc = c - lb * 6;
+    if (c >= sb) return;
+#pragma unroll 4
+    for (int r = threadIdx.x / 64; r < sb; r += 4) {
+        const int la = r / 6, rr = r - la * 6;
         double val = 0.0;
         if (is_f) {
             const int32_t id = mp[la * bw + lb];
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blo
             if (id >= 0) val = la <= lb ? blocks[36 * (size_t)id + rr * 6 + cc] : blocks[36 * (size_t)id + cc * 6 + rr];
             else if (id == -2 && r == c) val = 1.0;
         }
-        dst[e] = val;
+        dst[(size_t)r * sb + c] = val;
     }
 }
 
