@@ -106,11 +106,11 @@ void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t st
 // zeroed afterwards (the status words of the next iteration)
 void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq,
                     unsigned long long seq);
-// The iteration's two final sums in one launch: out5[0..4] = the five step scalars of the back-substitution partials
-// (sums, last one a max), out_cost = 0.5 sum cost_part; host_dst != NULL: then the publication (see launch_publish)
-void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cost_part, uint32_t n_cost,
-                      double* out_cost, double* pub_src, int n_pub, int clear_first, int clear_n, double* host_dst,
-                      unsigned long long* host_seq, unsigned long long seq);
+// The iteration's final sums in one launch: out5[0..4] = the five step scalars of the back-substitution partials (sums,
+// last one a max), out_cam5 the same of the camera-update partials, out_cost = 0.5 sum cost_part; host_dst != NULL: then the publication (see launch_publish)
+void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cam5, uint32_t n_cam5, double* out_cam5,
+                      const double* cost_part, uint32_t n_cost, double* out_cost, double* pub_src, int n_pub, int clear_first, int clear_n,
+                      double* host_dst, unsigned long long* host_seq, unsigned long long seq);
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
@@ -150,9 +150,12 @@ void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, cons
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,
                      LmDiag lm, const int32_t* diag_block, double* S, double* lc);
 
+// cam_part[cam_update_blocks(n_cam)][5]: per-workgroup partials of the camera share of the step scalars (launch_step_sums
+// adds them into SC_MCC_CAM .. SC_GMAX_CAM)
+inline uint32_t cam_update_blocks(uint32_t n_cam) { return (n_cam * 6 + 255) / 256; }
 void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams,
                        const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid, const double* campre,
-                       double* cams_out, double* dc_full, double* dcw /* [n_cam][6]: M dc_rot | dc_t */, double* scal);
+                       double* cams_out, double* dc_full, double* dcw /* [n_cam][6]: M dc_rot | dc_t */, double* cam_part);
 
 void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
                     const double* ar, const double* campre, const double* dcw,

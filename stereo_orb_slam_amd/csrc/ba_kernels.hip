@@ -289,31 +289,41 @@ __global__ __launch_bounds__(1024) void sum5_kernel(const double* __restrict__ i
 // The two one-workgroup sums that end an iteration in one launch: the back-substitution's five step scalars (as
 // sum5_kernel) and the candidate cost (as sum_strided_kernel, stride 1, scale 0.5), then the optional publication.
 __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __restrict__ part5, uint32_t n5, double* __restrict__ out5,
+                                                             const double* __restrict__ cam5, uint32_t n_cam5, double* __restrict__ out_cam5,
                                                              const double* __restrict__ cost_part, uint32_t n_cost,
                                                              double* __restrict__ out_cost, const Publish pb)
 {
-    __shared__ double red[16 * 6];
+    __shared__ double red[16 * 11];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, mx = 0.0, sc = 0.0;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, cx = 0.0;
     for (uint32_t i = threadIdx.x; i < n5; i += 1024) {
         const double* v = part5 + 5 * (size_t)i;
         s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
         mx = fmax(mx, v[4]);
     }
+    for (uint32_t i = threadIdx.x; i < n_cam5; i += 1024) {
+        const double* v = cam5 + 5 * (size_t)i;
+        c0 += v[0]; c1 += v[1]; c2 += v[2]; c3 += v[3];
+        cx = fmax(cx, v[4]);
+    }
     for (uint32_t i = threadIdx.x; i < n_cost; i += 1024) sc += cost_part[i];
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); mx = wave_max(mx); sc = wave_sum(sc);
+    c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); c3 = wave_sum(c3); cx = wave_max(cx);
     if (threadIdx.x % kWave == 0) {
-        double* o = red + (threadIdx.x / kWave) * 6;
+        double* o = red + (threadIdx.x / kWave) * 11;
         o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = mx; o[5] = sc;
+        o[6] = c0; o[7] = c1; o[8] = c2; o[9] = c3; o[10] = cx;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0, c = 0.0, d = 0.0, e = 0.0, f = 0.0;
-        for (int w = 0; w < 16; w++) {
-            a += red[w * 6]; b += red[w * 6 + 1]; c += red[w * 6 + 2]; d += red[w * 6 + 3]; e = fmax(e, red[w * 6 + 4]);
-            f += red[w * 6 + 5];
-        }
-        out5[0] = a; out5[1] = b; out5[2] = c; out5[3] = d; out5[4] = e;
-        out_cost[0] = 0.5 * f;
+    if (threadIdx.x < 11) {
+        // lane k adds (or maximises) value k of the sixteen wave partials, in wave order
+        const int k = threadIdx.x;
+        const bool is_max = k == 4 || k == 10;
+        double a = 0.0;
+        for (int w = 0; w < 16; w++) a = is_max ? fmax(a, red[w * 11 + k]) : a + red[w * 11 + k];
+        if (k < 5) out5[k] = a;
+        else if (k == 5) out_cost[0] = 0.5 * a;
+        else out_cam5[k - 6] = a;
     }
     publish_tail(pb);
 }
@@ -864,19 +874,20 @@ __global__ __launch_bounds__(256) void ba_cam_damp_kernel(uint32_t n_free, const
     S[36 * (size_t)diag_block[f] + a * 7] += lam;
 }
 
-// candidate cameras, full-length camera step, camera share of the step scalars (one workgroup)
-__global__ __launch_bounds__(1024) void ba_cam_update_kernel(uint32_t n_cam, const int32_t* __restrict__ cam_free,
+// candidate cameras, full-length camera step, per-workgroup partials of the camera share of the step scalars
+__global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, const int32_t* __restrict__ cam_free,
                                                             const double* __restrict__ cams,
                                                             const double* __restrict__ dc_free,
                                                             const double* __restrict__ lc, const double* __restrict__ gc_red,
                                                             const double* __restrict__ lin_resid,
                                                             const double* __restrict__ campre,
                                                             double* __restrict__ cams_out, double* __restrict__ dc_full,
-                                                            double* __restrict__ dcw, double* __restrict__ scal)
+                                                            double* __restrict__ dcw, double* __restrict__ cam_part)
 {
-    __shared__ double red[16 * 5];
+    __shared__ double red[4 * 5];
     double mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_cam * 6; i += 1024) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_cam * 6) {
         const uint32_t c = i / 6, a = i % 6;
         const int32_t f = cam_free[c];
         const double x = cams[i];
@@ -917,8 +928,9 @@ __global__ __launch_bounds__(1024) void ba_cam_update_kernel(uint32_t n_cam, con
     __syncthreads();
     if (threadIdx.x == 0) {
         double a = 0, b = 0, c = 0, d = 0, e = 0;
-        for (int w = 0; w < 16; w++) { a += red[w * 5]; b += red[w * 5 + 1]; c += red[w * 5 + 2]; d += red[w * 5 + 3]; e = fmax(e, red[w * 5 + 4]); }
-        scal[SC_MCC_CAM] = a; scal[SC_STEP2_CAM] = b; scal[SC_X2_CAM] = c; scal[SC_GDOT_CAM] = d; scal[SC_GMAX_CAM] = e;
+        for (int w = 0; w < 4; w++) { a += red[w * 5]; b += red[w * 5 + 1]; c += red[w * 5 + 2]; d += red[w * 5 + 3]; e = fmax(e, red[w * 5 + 4]); }
+        double* o = cam_part + 5 * (size_t)blockIdx.x;   // summed over the workgroups by ba_step_sums
+        o[0] = a; o[1] = b; o[2] = c; o[3] = d; o[4] = e;
     }
 }
 
@@ -1062,11 +1074,11 @@ void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clea
     hipLaunchKernelGGL(ba_publish_kernel, dim3(1), dim3(64), 0, s, Publish{src, host_dst, host_seq, seq, n, clear_first, clear_n});
 }
 
-void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cost_part, uint32_t n_cost,
-                      double* out_cost, double* pub_src, int n_pub, int clear_first, int clear_n, double* host_dst,
-                      unsigned long long* host_seq, unsigned long long seq)
+void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cam5, uint32_t n_cam5, double* out_cam5,
+                      const double* cost_part, uint32_t n_cost, double* out_cost, double* pub_src, int n_pub, int clear_first, int clear_n,
+                      double* host_dst, unsigned long long* host_seq, unsigned long long seq)
 {
-    hipLaunchKernelGGL(ba_step_sums_kernel, dim3(1), dim3(1024), 0, s, part5, n5, out5, cost_part, n_cost, out_cost,
+    hipLaunchKernelGGL(ba_step_sums_kernel, dim3(1), dim3(1024), 0, s, part5, n5, out5, cam5, n_cam5, out_cam5, cost_part, n_cost, out_cost,
                        Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
 }
 
@@ -1158,10 +1170,10 @@ void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double
 
 void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams,
                        const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid, const double* campre,
-                       double* cams_out, double* dc_full, double* dcw, double* scal)
+                       double* cams_out, double* dc_full, double* dcw, double* cam_part)
 {
-    hipLaunchKernelGGL(ba_cam_update_kernel, dim3(1), dim3(1024), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red, lin_resid, campre,
-                       cams_out, dc_full, dcw, scal);
+    hipLaunchKernelGGL(ba_cam_update_kernel, dim3(cam_update_blocks(n_cam)), dim3(256), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red,
+                       lin_resid, campre, cams_out, dc_full, dcw, cam_part);
 }
 
 void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,

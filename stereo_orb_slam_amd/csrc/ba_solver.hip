@@ -96,6 +96,7 @@ struct soslam_ba {
     // state and work buffers
     DevBuf<double> cams[2], pts[2];
     int cur = 0;
+    DevBuf<double> cam_part;            // [cam_update_blocks][5] partials of the camera share of the step scalars
     DevBuf<double> campre, campre_c, ar, dcw, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
     DevBuf<double> lin_resid, lin_work, dense, band, bandT, band_dinv, cr_ws;
     DevBuf<double> reduce_own;          // library-owned reduce buffer
@@ -598,6 +599,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         return SOSLAM_ERR_INVALID_ARGUMENT;
     }
     SOSLAM_CHECK(h->campre_c.alloc((size_t)n_cam * kPoseStride));
+    SOSLAM_CHECK(h->cam_part.alloc(5 * (size_t)cam_update_blocks(n_cam)));
     SOSLAM_CHECK(h->ar.alloc((size_t)n_obs * kArRow));
     SOSLAM_CHECK(h->dcw.alloc((size_t)n_cam * 6));
     SOSLAM_CHECK(h->tile_part.alloc((size_t)h->n_tiles * kTileVals));
@@ -791,7 +793,7 @@ int take_step(soslam_ba* h, double radius)
             }
         }
         launch_cam_update(s, h->n_cam, h->cam_free.p, h->cams[h->cur].p, h->dc_free.p, h->lc.p, h->gc_red(), resid, h->campre.p,
-                          h->cams[h->cur ^ 1].p, h->dc_full.p, h->dcw.p, h->scalp());
+                          h->cams[h->cur ^ 1].p, h->dc_full.p, h->dcw.p, h->cam_part.p);
     }
     {
         StageScope sc(h, SOSLAM_STAGE_BACKSUB);
@@ -809,7 +811,8 @@ int take_step(soslam_ba* h, double radius)
         // one launch for the back-substitution's step scalars and the candidate cost; on a single rank nothing follows
         // it, so it also hands the iteration's scalars to the host
         if (h->world <= 1) published = ++h->publish_seq;
-        launch_step_sums(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS, h->cost_part.p, h->n_tiles,
+        launch_step_sums(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS, h->cam_part.p, cam_update_blocks(h->n_cam),
+                         h->scalp() + SC_MCC_CAM, h->cost_part.p, h->n_tiles,
                          h->scalp() + SC_CAND_COST, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, published ? h->host_raw : nullptr,
                          h->host_seq, published);
     }
