@@ -1210,6 +1210,7 @@ int soslam_ba_set_allreduce(soslam_ba* h, soslam_allreduce_fn fn, void* user, in
 {
     if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return SOSLAM_ERR_INVALID_ARGUMENT;
     h->allreduce = fn; h->allreduce_user = user; h->rank = rank; h->world = world;
+    h->linearized = false; h->x_cost_known = false;   // sums over a different set of ranks from now on
     return SOSLAM_OK;
 }
 
