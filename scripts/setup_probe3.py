@@ -1,0 +1,8 @@
+import sys
+sys.path.insert(0, "/root/repo")
+from stereo_orb_slam_amd import ba, synth
+p = synth.generate_ba(3)
+with ba.BundleAdjustment(ba.default_options(max_iterations=2)) as h:
+    h.load(p); h.solve()
+    print("---- second load", file=sys.stderr, flush=True)
+    h.load(p)
