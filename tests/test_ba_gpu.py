@@ -391,6 +391,22 @@ def test_band_solver_widths(gpu, oracle_lib, solver, track):
     assert sc[1] == pytest.approx(ref["model_cost_change"], rel=1e-7)
 
 
+@pytest.mark.parametrize("n_cam", [4, 6, 8, 10, 12, 18, 20, 34, 36, 66, 130])
+def test_cyclic_reduction_tree_shapes(gpu, oracle_lib, n_cam):
+    """Block half-bandwidth 2 with 2 .. 65 super-blocks: every shape of the cyclic-reduction tree - with and without a
+    left-over level below the top (cr_top / cr_top2), level pairs (cr_fwd2 / cr_bwd2) with missing right neighbours, odd
+    and even node counts - as a direct solve (solver 3) against the oracle's step."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, n_cam=n_cam, n_pt=40 * n_cam, track_mode=0, track_len=3, spacing=0.4)
+    ref = oracle_lib.step(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, 1e4)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=3)) as h:
+        h.load(p)
+        h.debug_step(1e4)
+        dc, dp = h.debug_read(L.DBG_STEP_CAM), h.debug_read(L.DBG_STEP_POINT)
+    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-6, atol=1e-9 * np.abs(ref["dc"]).max())
+    np.testing.assert_allclose(dp, ref["dp"], rtol=1e-6, atol=1e-9 * np.abs(ref["dp"]).max())
+
+
 def _merge_problems(synth, a, b):
     """Points of b appended to a (same cameras)."""
     assert a.n_cam == b.n_cam and np.array_equal(a.poses_wc, b.poses_wc)
