@@ -32,7 +32,8 @@ enum {
     SC_LIN_ITERS = 13, SC_LIN_RESID = 14, SC_LIN_STATUS = 15,
     SC_SCHUR_STATUS = 16,                             // rank-local; spread through the candidate cost (launch_status_poison);
                                                       // next to the solver's slots: one memset clears all four per iteration
-    SC_COUNT = 17
+    SC_GATE = 17,                                     // 1: the device accepted the step and has linearised at the candidate
+    SC_COUNT = 18
 };
 
 struct Tile {      // one workgroup of ba_linearize / ba_cost
@@ -89,7 +90,7 @@ void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, doub
 
 void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
                       const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
-                      double* ar, double* tile_part);
+                      double* ar, double* tile_part, const double* gate = nullptr /* != NULL: run only if *gate != 0 */);
 
 // parity tests: residual (n_obs*4), J_c (n_obs*24), J_p (n_obs*12) of every observation, internal observation order
 void launch_debug_rows(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
@@ -108,16 +109,19 @@ void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clea
                     unsigned long long seq);
 // The iteration's final sums in one launch: out5[0..4] = the five step scalars of the back-substitution partials (sums,
 // last one a max), out_cam5 the same of the camera-update partials, out_cost = 0.5 sum cost_part; host_dst != NULL: then the publication (see launch_publish)
+// gate != NULL: *gate = the LM acceptance test (status words all zero, finite positive model change, (x_cost - candidate
+// cost) / model change > min_relative_decrease) if gate_enabled, else 0 - for launches enqueued behind this one
 void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cam5, uint32_t n_cam5, double* out_cam5,
-                      const double* cost_part, uint32_t n_cost, double* out_cost, double* pub_src, int n_pub, int clear_first, int clear_n,
+                      const double* cost_part, uint32_t n_cost, double* out_cost, double* gate, const double* status, double x_cost,
+                      double min_relative_decrease, int gate_enabled, double* pub_src, int n_pub, int clear_first, int clear_n,
                       double* host_dst, unsigned long long* host_seq, unsigned long long seq);
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
-                       const double* tile_part, double* B /* [F][36] */, double* gc /* [F][6] */);
+                       const double* tile_part, double* B /* [F][36] */, double* gc /* [F][6] */, const double* gate = nullptr);
 
 void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
-                         const double* ar, const double* campre, double* C, double* gp);
+                         const double* ar, const double* campre, double* C, double* gp, const double* gate = nullptr);
 
 void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacobi, double* sp);
 

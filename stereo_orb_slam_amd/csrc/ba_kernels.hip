@@ -51,8 +51,10 @@ __global__ __launch_bounds__(64) void ba_pose_prepare_kernel(uint32_t n_cam, con
 __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
     const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
     const double* __restrict__ campre, const double* __restrict__ pts, const int32_t* __restrict__ cam_free,
-    const Proj P, const double delta, double* __restrict__ ar_out, double* __restrict__ tile_part)
+    const Proj P, const double delta, double* __restrict__ ar_out, double* __restrict__ tile_part,
+    const double* __restrict__ gate)
 {
+    if (gate && *gate == 0.0) return;   // speculative launch (see ba_step_sums_kernel): the step was not accepted
     // Row-per-lane stores would touch 64 different lines per instruction; instead each wave stages its 64 rows
     // in LDS (rows padded to 18 doubles: conflict-free ds_write_b128) and writes them back out as whole
     // 1-KiB pieces, 16 contiguous bytes per lane.
@@ -224,6 +226,13 @@ __global__ __launch_bounds__(kTileThreads) void ba_cost_kernel(
 }
 
 // fixed-order sum of a strided column: one workgroup, each lane a fixed subsequence, then a fixed tree
+struct StepGate {   // the acceptance test of the LM loop for ba_step_sums_kernel (gate == nullptr: none)
+    double* gate;            // out: 1.0 accepted, 0.0 not (or speculation disabled)
+    const double* status;    // scal + SC_LIN_ITERS: [2] = SC_LIN_STATUS, [3] = SC_SCHUR_STATUS
+    double x_cost, min_relative_decrease;
+    int enabled;
+};
+
 struct Publish {   // optional tail of a one-workgroup kernel: n <= 64 doubles to pinned host memory, then a sequence number;
                    // the slots [clear_first, clear_first + clear_n) of src (status words) are zeroed for the next iteration
     double* src;
@@ -291,9 +300,10 @@ __global__ __launch_bounds__(1024) void sum5_kernel(const double* __restrict__ i
 __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __restrict__ part5, uint32_t n5, double* __restrict__ out5,
                                                              const double* __restrict__ cam5, uint32_t n_cam5, double* __restrict__ out_cam5,
                                                              const double* __restrict__ cost_part, uint32_t n_cost,
-                                                             double* __restrict__ out_cost, const Publish pb)
+                                                             double* __restrict__ out_cost, const StepGate sg, const Publish pb)
 {
     __shared__ double red[16 * 11];
+    __shared__ double fin[11];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, mx = 0.0, sc = 0.0;
     double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, cx = 0.0;
     for (uint32_t i = threadIdx.x; i < n5; i += 1024) {
@@ -321,9 +331,22 @@ __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __rest
         const bool is_max = k == 4 || k == 10;
         double a = 0.0;
         for (int w = 0; w < 16; w++) a = is_max ? fmax(a, red[w * 11 + k]) : a + red[w * 11 + k];
+        if (k == 5) a *= 0.5;
+        fin[k] = a;
         if (k < 5) out5[k] = a;
-        else if (k == 5) out_cost[0] = 0.5 * a;
+        else if (k == 5) out_cost[0] = a;
         else out_cam5[k - 6] = a;
+    }
+    if (sg.gate) {
+        // The LM loop's acceptance test, on the device: the host has already enqueued the linearisation at the candidate
+        // behind this kernel, gated by this word, so an accepted step goes on without waiting for the host (which reads
+        // the same word and follows it).  Same operands and operations as run_lm.
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double mcc = fin[0] + fin[6], cand = fin[5];
+            const bool ok = sg.status[2] == 0.0 && sg.status[3] == 0.0 && isfinite(mcc) && isfinite(cand) && mcc > 0.0;
+            *sg.gate = (sg.enabled && ok && (sg.x_cost - cand) / mcc > sg.min_relative_decrease) ? 1.0 : 0.0;
+        }
     }
     publish_tail(pb);
 }
@@ -333,8 +356,10 @@ __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __rest
 __global__ __launch_bounds__(64) void ba_cam_reduce_kernel(const uint32_t* __restrict__ cam_tile_start,
                                                            const int32_t* __restrict__ cam_free,
                                                            const double* __restrict__ tile_part,
-                                                           double* __restrict__ B, double* __restrict__ gc)
+                                                           double* __restrict__ B, double* __restrict__ gc,
+    const double* __restrict__ gate)
 {
+    if (gate && *gate == 0.0) return;   // speculative launch (see ba_step_sums_kernel): the step was not accepted
     const uint32_t cam = blockIdx.x;
     const int32_t f = cam_free[cam];
     const int v = threadIdx.x;
@@ -359,8 +384,10 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n
                                                                       const uint32_t* __restrict__ q_cam,
                                                                       const double* __restrict__ ar,
                                                                       const double* __restrict__ campre,
-                                                                      double* __restrict__ C, double* __restrict__ gp)
+                                                                      double* __restrict__ C, double* __restrict__ gp,
+    const double* __restrict__ gate)
 {
+    if (gate && *gate == 0.0) return;   // speculative launch (see ba_step_sums_kernel): the step was not accepted
     // kBacksubLanes lanes per point share its observations (a gather: more rows in flight), fixed butterfly at the end.
     // J_p = A R is rebuilt from the compact row and the camera's rotation (cached: 72 B per camera).
     const uint32_t p = (blockIdx.x * kPointBlock + threadIdx.x) / kBacksubLanes;
@@ -1033,11 +1060,11 @@ void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, doub
 
 void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
                       const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
-                      double* ar, double* tile_part)
+                      double* ar, double* tile_part, const double* gate)
 {
     if (!n_tiles) return;
     hipLaunchKernelGGL(ba_linearize_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre, pts,
-                       cam_free, P, delta, ar, tile_part);
+                       cam_free, P, delta, ar, tile_part, gate);
 }
 
 void launch_debug_rows(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
@@ -1075,10 +1102,12 @@ void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clea
 }
 
 void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cam5, uint32_t n_cam5, double* out_cam5,
-                      const double* cost_part, uint32_t n_cost, double* out_cost, double* pub_src, int n_pub, int clear_first, int clear_n,
+                      const double* cost_part, uint32_t n_cost, double* out_cost, double* gate, const double* status, double x_cost,
+                      double min_relative_decrease, int gate_enabled, double* pub_src, int n_pub, int clear_first, int clear_n,
                       double* host_dst, unsigned long long* host_seq, unsigned long long seq)
 {
     hipLaunchKernelGGL(ba_step_sums_kernel, dim3(1), dim3(1024), 0, s, part5, n5, out5, cam5, n_cam5, out_cam5, cost_part, n_cost, out_cost,
+                       StepGate{gate, status, x_cost, min_relative_decrease, gate_enabled},
                        Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
 }
 
@@ -1088,18 +1117,18 @@ void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out)
 }
 
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
-                       const double* tile_part, double* B, double* gc)
+                       const double* tile_part, double* B, double* gc, const double* gate)
 {
     if (!n_cam) return;
-    hipLaunchKernelGGL(ba_cam_reduce_kernel, dim3(n_cam), dim3(64), 0, s, cam_tile_start, cam_free, tile_part, B, gc);
+    hipLaunchKernelGGL(ba_cam_reduce_kernel, dim3(n_cam), dim3(64), 0, s, cam_tile_start, cam_free, tile_part, B, gc, gate);
 }
 
 void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
-                         const double* ar, const double* campre, double* C, double* gp)
+                         const double* ar, const double* campre, double* C, double* gp, const double* gate)
 {
     if (!n_pt) return;
     hipLaunchKernelGGL(ba_point_reduce_kernel, dim3(backsub_blocks(n_pt)), dim3(kPointBlock), 0, s, n_pt, pt_start, pt_obs, q_cam, ar,
-                       campre, C, gp);
+                       campre, C, gp, gate);
 }
 
 void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacobi, double* sp)

@@ -722,10 +722,11 @@ void run_schur(soslam_ba* h, const LmDiag& lm)
 constexpr uint32_t kPcgMultiMinRows = 64;   // below this one workgroup does a whole PCG iteration faster than three launches
 
 // one trust-region step from the current linearisation: reduced system, solve, candidate, candidate cost
-int take_step(soslam_ba* h, double radius)
+int take_step(soslam_ba* h, double radius, bool speculate = false)
 {
     hipStream_t s = h->stream;
     unsigned long long published = 0;   // sequence number if the scalars were already handed to the host
+    bool speculated = false;            // the linearisation at the candidate is enqueued behind the acceptance test
     const LmDiag lm = lm_diag(h, radius);
     {
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
@@ -811,10 +812,28 @@ int take_step(soslam_ba* h, double radius)
         // one launch for the back-substitution's step scalars and the candidate cost; on a single rank nothing follows
         // it, so it also hands the iteration's scalars to the host
         if (h->world <= 1) published = ++h->publish_seq;
+        // speculation (single rank, cost at x known): the kernel decides acceptance itself and the linearisation at the
+        // candidate is enqueued right behind it, gated by that decision - the GPU does not wait for the host's round trip
+        const bool spec = speculate && h->world <= 1 && h->x_cost_known;
+        static_assert(SC_LIN_STATUS == SC_LIN_ITERS + 2 && SC_SCHUR_STATUS == SC_LIN_ITERS + 3, "status words as StepGate reads them");
         launch_step_sums(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS, h->cam_part.p, cam_update_blocks(h->n_cam),
-                         h->scalp() + SC_MCC_CAM, h->cost_part.p, h->n_tiles,
-                         h->scalp() + SC_CAND_COST, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, published ? h->host_raw : nullptr,
-                         h->host_seq, published);
+                         h->scalp() + SC_MCC_CAM, h->cost_part.p, h->n_tiles, h->scalp() + SC_CAND_COST, h->scalp() + SC_GATE,
+                         h->scalp() + SC_LIN_ITERS, h->x_cost, h->opt.min_relative_decrease, spec ? 1 : 0, h->tail(), 4 + SC_COUNT,
+                         4 + SC_LIN_ITERS, 4, published ? h->host_raw : nullptr, h->host_seq, published);
+        speculated = spec;
+    }
+    if (speculated) {
+        const double* gate = h->scalp() + SC_GATE;
+        {
+            StageScope sc(h, SOSLAM_STAGE_LINEARIZE);
+            launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->cam_free.p, h->proj,
+                             h->opt.huber_delta, h->ar.p, h->tile_part.p, gate);
+            launch_cam_reduce(s, h->n_cam, h->cam_tile_start.p, h->cam_free.p, h->tile_part.p, h->B.p, h->gc.p, gate);
+        }
+        {
+            StageScope sc(h, SOSLAM_STAGE_POINT_REDUCE);
+            launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre_c.p, h->C.p, h->gp.p, gate);
+        }
     }
     {
         StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
@@ -909,9 +928,17 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         if (it >= max_it) { sum.termination = SOSLAM_TERM_MAX_ITERATIONS; break; }
         if (check && h->radius < o.min_radius) { sum.termination = SOSLAM_TERM_MIN_RADIUS; break; }
         if (check && o.max_solver_time_seconds > 0.0 && now_sec() - t0 > o.max_solver_time_seconds) { sum.termination = SOSLAM_TERM_TIME; break; }
+        if (!h->linearized) SOSLAM_CHECK(linearize(h));   // only after a speculative linearisation the host did not follow
         const double radius = h->radius;
-        SOSLAM_CHECK(take_step(h, radius));
+        SOSLAM_CHECK(take_step(h, radius, true));
         StepScalars sc = read_scalars(h);
+        // the device accepted the step and has already linearised at the candidate (speculation, see take_step); if the
+        // host ends up keeping x after all, the linearisation at x has to be made again
+        bool dev_linearized = h->host_scal[SC_GATE] != 0.0;
+        struct Relinearize {
+            soslam_ba* h; bool* armed;
+            ~Relinearize() { if (*armed) { h->linearized = false; } }
+        } relin{h, &dev_linearized};
         if (h->x_cost_known) sc.x_cost = h->x_cost;   // the device slot is stale then (see linearize)
         h->x_cost = sc.x_cost;
         h->x_cost_known = true;
@@ -970,7 +997,13 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
             h->campre_current = true;
             h->x_cost = sc.cand_cost;
             h->x_cost_known = true;
-            SOSLAM_CHECK(linearize(h));
+            if (dev_linearized) {
+                dev_linearized = false;      // consumed: B, g_c, C, g_p and the compact rows are those of the new point
+                h->campre_current = false;
+                h->linearized = true;
+            } else {
+                SOSLAM_CHECK(linearize(h));
+            }
             double f = 1.0 - std::pow(2.0 * rel - 1.0, 3.0);
             if (f < 1.0 / 3.0) f = 1.0 / 3.0;
             h->radius = std::min(o.max_radius, h->radius / f);
