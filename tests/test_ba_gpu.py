@@ -407,6 +407,32 @@ def test_cyclic_reduction_tree_shapes(gpu, oracle_lib, n_cam):
     np.testing.assert_allclose(dp, ref["dp"], rtol=1e-6, atol=1e-9 * np.abs(ref["dp"]).max())
 
 
+def test_termination_after_the_device_accepted_a_step(gpu, prob1):
+    """On one rank the acceptance test runs on the device and the linearisation at the candidate is enqueued behind it
+    (speculation).  A termination test that fires on such a step makes the host keep x although the device has already
+    linearised at the candidate: the next call has to start from a fresh linearisation at x.  Checked by continuing the
+    terminated handle for one iteration and comparing with a new handle started at the same point and radius."""
+    ba, synth, L = gpu
+    with ba.BundleAdjustment(ba.default_options(function_tolerance=0.5, max_iterations=30)) as h:
+        h.load(prob1)
+        s = h.solve()
+        assert ba.summary_dict(s)["termination_name"].lower().startswith("function"), ba.summary_dict(s)["termination_name"]
+        log = h.iteration_log()
+        assert log[-1].valid and log[-1].candidate_cost < log[-1].cost        # a step the device accepted
+        radius = log[-1].radius
+        cams, pts = h.get_state()
+        h.iterate(1)
+        a = h.iteration_log()[-1]
+    with ba.BundleAdjustment(ba.default_options(initial_radius=radius)) as g:
+        g.load(prob1)
+        g.set_state(cams, pts)
+        g.iterate(1)
+        b = g.iteration_log()[-1]
+    assert a.cost == pytest.approx(b.cost, rel=1e-13)
+    assert a.candidate_cost == pytest.approx(b.candidate_cost, rel=1e-11)
+    assert a.model_cost_change == pytest.approx(b.model_cost_change, rel=1e-9)
+
+
 def _merge_problems(synth, a, b):
     """Points of b appended to a (same cameras)."""
     assert a.n_cam == b.n_cam and np.array_equal(a.poses_wc, b.poses_wc)
