@@ -199,6 +199,31 @@ enum { SOSLAM_REDUCE_SUM = 0, SOSLAM_REDUCE_MAX = 1 };
  */
 typedef int (*soslam_allreduce_fn)(void* user, void* device_buffer, uint64_t count, int32_t op, void* stream);
 int soslam_ba_set_allreduce(soslam_ba* h, soslam_allreduce_fn fn, void* user, int32_t rank, int32_t world);
+/*
+ * The same exchange through HOST memory, for hosts whose collective cannot take device pointers (MPI without device
+ * support; gloo in the tests): the library copies the range to a pinned buffer of its own on its own stream, calls fn
+ * for an in-place all-reduce of that host range, and uploads the result.  Wins over a device callback; the RCCL leg wins
+ * over both.
+ */
+typedef int (*soslam_host_allreduce_fn)(void* user, double* host_buffer, uint64_t count, int32_t op);
+int soslam_ba_set_host_allreduce(soslam_ba* h, soslam_host_allreduce_fn fn, void* user, int32_t rank, int32_t world);
+/*
+ * The library's own collective leg: RCCL over xGMI (librccl.so.1 bound with dlopen at first use - no link-time
+ * dependency).  One process per GPU; rank 0 draws a unique id (ncclGetUniqueId) and hands its 128 bytes to the other
+ * ranks by whatever side channel the host has (MPI_Bcast, a file, a torch.distributed store); then EVERY rank calls
+ * soslam_ba_init_rccl (ncclCommInitRank on the handle's device: a collective call).  From then on the two all-reduces
+ * of an LM iteration are ncclAllReduce calls in place on the handle's stream; a callback set with
+ * soslam_ba_set_allreduce is ignored.  The communicator is destroyed with the handle.
+ */
+#define SOSLAM_RCCL_UNIQUE_ID_BYTES 128
+int soslam_rccl_get_unique_id(void* id128);
+int soslam_ba_init_rccl(soslam_ba* h, const void* id128, int32_t rank, int32_t world);
+/*
+ * After a sharded solve: poses[n_cam*6] (replicated, may be NULL) and the points of ALL ranks, points_global[n_pt_global*3],
+ * on every rank - this rank's shard is the global range [shard_begin, shard_begin + n_pt).  One all-reduce (sum of
+ * zero-padded shards) through the RCCL leg or the callback; with one rank it is a plain download.
+ */
+int soslam_ba_get_state_global(soslam_ba* h, double* poses, uint32_t n_pt_global, uint32_t shard_begin, double* points_global);
 /* The per-iteration reduce payload (reduced camera system + gradient + scalars) lives in one device
  * buffer.  Query its size after set_problem; optionally make the library use a caller-owned buffer
  * (e.g. a torch tensor) of at least that many f64 so the host can alias it. */
@@ -229,15 +254,18 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
 
 enum {
     SOSLAM_DBG_RESIDUALS = 0,   /* n_obs*4  f64, caller's observation order, loss-corrected */
-    SOSLAM_DBG_JAC_CAM = 1,     /* n_obs*24 f64, 4x6 row-major, zero for fixed cameras (rebuilt from the compact rows) */
+    SOSLAM_DBG_JAC_CAM = 1,     /* n_obs*24 f64, 4x6 row-major, zero for fixed cameras (J_c = [A D | A] from ba_linearize's own r, A, D) */
     SOSLAM_DBG_JAC_POINT = 2,   /* n_obs*12 f64, 4x3 row-major */
     SOSLAM_DBG_COST = 3,        /* 1 f64: cost at the current state */
     SOSLAM_DBG_S_DENSE = 4,     /* (6F)^2 f64 row-major, both triangles, damping included (last step) */
     SOSLAM_DBG_RHS = 5,         /* 6F f64 */
     SOSLAM_DBG_STEP_CAM = 6,    /* n_cam*6 f64 (zero rows for fixed cameras) */
     SOSLAM_DBG_STEP_POINT = 7,  /* n_pt*3 f64, caller's point order */
-    SOSLAM_DBG_STEP_SCALARS = 8 /* 6 f64: cost, model_cost_change, candidate_cost, step_norm, linear-solver
+    SOSLAM_DBG_STEP_SCALARS = 8,/* 6 f64: cost, model_cost_change, candidate_cost, step_norm, linear-solver
                                    iterations, linear-solver status (0 ok) */
+    SOSLAM_DBG_COMPACT_ROWS = 9 /* n_obs*9 f64, caller's observation order: the compact row [Gxx Gxy Gxz Gyy Gyz Gzz | hx hy hz]
+                                   (G = A^T A, h = A^T r) of every observation AS STORED by ba_linearize - the array every
+                                   later kernel of the iteration reads */
 };
 /* Evaluate at the current state without advancing it: linearise, and for the S/RHS/STEP items take one
  * trust-region step with `radius` and scaling from this linearisation (mirrors oracle_ba_step). */

@@ -768,11 +768,12 @@ int oracle_ba_solve(uint32_t n_cam, uint32_t n_pt, uint32_t n_obs,
         double mcc = lin == 0 ? model_cost_change(&w) : 0.0;
         it.model_cost_change = mcc;
         if (lin != 0 || !(mcc > 0.0)) {
-            /* invalid step: treated as a rejected step with no gain */
+            /* invalid step (TrustRegionMinimizer::HandleInvalidStep) */
             it.valid = 0;
             if (log) log[iterations] = it;
             if (opt->check_termination && ++invalid_run >= 5) { term = ORACLE_TERM_INVALID_STEPS; break; }
-            radius /= decrease_factor; decrease_factor *= 2.0;
+            /* LevenbergMarquardtStrategy::StepIsInvalid: radius *= 0.5, the rejected-step factor is left alone */
+            radius *= 0.5;
             continue;
         }
         invalid_run = 0; it.valid = 1;

@@ -25,8 +25,9 @@ TERM_NAMES = ["max_iterations", "parameter_tolerance", "function_tolerance", "gr
               "invalid_steps", "time"]
 KERNEL_LINEARIZE, KERNEL_COST, KERNEL_POINT_REDUCE, KERNEL_SCHUR, KERNEL_BACKSUB = range(5)
 (DBG_RESIDUALS, DBG_JAC_CAM, DBG_JAC_POINT, DBG_COST, DBG_S_DENSE, DBG_RHS, DBG_STEP_CAM, DBG_STEP_POINT,
- DBG_STEP_SCALARS) = range(9)
+ DBG_STEP_SCALARS, DBG_COMPACT_ROWS) = range(10)
 REDUCE_SUM, REDUCE_MAX = 0, 1
+RCCL_UNIQUE_ID_BYTES = 128
 
 
 class BaOptions(C.Structure):
@@ -78,6 +79,7 @@ class SynthPgParams(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64, C.c_int32)
 
 # every symbol include/*.h declares; tests/test_cabi.py checks the library exports each one
 BA_SYMBOLS = [
@@ -85,6 +87,7 @@ BA_SYMBOLS = [
     "soslam_ba_destroy", "soslam_ba_set_options", "soslam_ba_set_projection", "soslam_ba_set_problem", "soslam_ba_set_state",
     "soslam_ba_get_state", "soslam_ba_solve", "soslam_ba_iterate", "soslam_ba_get_iteration_log",
     "soslam_ba_optimize", "soslam_ba_set_covisibility", "soslam_ba_set_allreduce", "soslam_ba_reduce_buffer_count", "soslam_ba_set_reduce_buffer",
+    "soslam_ba_set_host_allreduce", "soslam_rccl_get_unique_id", "soslam_ba_init_rccl", "soslam_ba_get_state_global",
     "soslam_ba_shard_range", "soslam_ba_time_kernel", "soslam_ba_debug_step", "soslam_ba_debug_read",
     "soslam_pose_from_global_matrix", "soslam_global_matrix_from_pose",
 ]
@@ -164,6 +167,10 @@ def lib():
     L.soslam_ba_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i32, i32]
     L.soslam_ba_reduce_buffer_count.argtypes = [vp, C.POINTER(u64)]
     L.soslam_ba_set_reduce_buffer.argtypes = [vp, vp, u64]
+    L.soslam_ba_set_host_allreduce.argtypes = [vp, HOST_ALLREDUCE_FN, vp, i32, i32]
+    L.soslam_rccl_get_unique_id.argtypes = [vp]
+    L.soslam_ba_init_rccl.argtypes = [vp, vp, i32, i32]
+    L.soslam_ba_get_state_global.argtypes = [vp, vp, u32, u32, vp]
     L.soslam_ba_shard_range.argtypes = [u32, i32, i32, C.POINTER(u32), C.POINTER(u32)]
     L.soslam_ba_shard_range.restype = None
     L.soslam_ba_time_kernel.argtypes = [vp, i32, i32, C.POINTER(C.c_float)]

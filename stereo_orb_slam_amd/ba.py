@@ -142,6 +142,34 @@ class BundleAdjustment:
         self._keep.append(cb)
         _lib.check(self._L.soslam_ba_set_allreduce(self._h, cb, None, rank, world), "soslam_ba_set_allreduce")
 
+    def set_host_allreduce(self, fn, rank: int, world: int):
+        """fn(host_array: np.ndarray[f64], op: int) -> int (0 = ok): in-place all-reduce of a host range the library
+        staged (soslam_ba_set_host_allreduce)."""
+        def tramp(user, buf, count, op):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(count,))
+                return int(fn(a, op) or 0)
+            except Exception as e:  # never let an exception cross the C boundary
+                print(f"[soslam] host all-reduce callback raised: {e!r}", flush=True)
+                return 1
+        cb = _lib.HOST_ALLREDUCE_FN(tramp)
+        self._keep.append(cb)
+        _lib.check(self._L.soslam_ba_set_host_allreduce(self._h, cb, None, rank, world), "soslam_ba_set_host_allreduce")
+
+    def init_rccl(self, unique_id: bytes, rank: int, world: int):
+        """The library's own RCCL leg (soslam_ba_init_rccl): every rank calls it with rank 0's unique id."""
+        if len(unique_id) != _lib.RCCL_UNIQUE_ID_BYTES:
+            raise ValueError("an RCCL unique id has 128 bytes")
+        buf = C.create_string_buffer(bytes(unique_id), _lib.RCCL_UNIQUE_ID_BYTES)
+        _lib.check(self._L.soslam_ba_init_rccl(self._h, C.cast(buf, C.c_void_p), rank, world), "soslam_ba_init_rccl")
+
+    def get_state_global(self, n_pt_global: int, shard_begin: int):
+        """Poses and the points of all ranks (soslam_ba_get_state_global)."""
+        c, p = np.zeros((self.n_cam, 6)), np.zeros((n_pt_global, 3))
+        _lib.check(self._L.soslam_ba_get_state_global(self._h, _lib.ptr(c), n_pt_global, shard_begin, _lib.ptr(p)),
+                   "soslam_ba_get_state_global")
+        return c, p
+
     # ---- stage-level access ---------------------------------------------------------------------------
     def time_kernel(self, kernel: int, reps: int = 20) -> float:
         ms = C.c_float()
@@ -156,11 +184,18 @@ class BundleAdjustment:
         shape = {
             _lib.DBG_RESIDUALS: (self.n_obs, 4), _lib.DBG_JAC_CAM: (self.n_obs, 4, 6), _lib.DBG_JAC_POINT: (self.n_obs, 4, 3),
             _lib.DBG_COST: (1,), _lib.DBG_S_DENSE: (6 * F, 6 * F), _lib.DBG_RHS: (6 * F,), _lib.DBG_STEP_CAM: (self.n_cam, 6),
-            _lib.DBG_STEP_POINT: (self.n_pt, 3), _lib.DBG_STEP_SCALARS: (6,),
+            _lib.DBG_STEP_POINT: (self.n_pt, 3), _lib.DBG_STEP_SCALARS: (6,), _lib.DBG_COMPACT_ROWS: (self.n_obs, 9),
         }[what]
         out = np.zeros(shape)
         _lib.check(self._L.soslam_ba_debug_read(self._h, what, _lib.ptr(out), out.nbytes), "soslam_ba_debug_read")
         return out
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 draws it, the other ranks receive it by a side channel)."""
+    buf = C.create_string_buffer(_lib.RCCL_UNIQUE_ID_BYTES)
+    _lib.check(_lib.lib().soslam_rccl_get_unique_id(C.cast(buf, C.c_void_p)), "soslam_rccl_get_unique_id")
+    return buf.raw
 
 
 def optimize(prob, options: BaOptions | None = None):

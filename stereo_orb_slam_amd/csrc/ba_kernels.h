@@ -27,7 +27,7 @@ enum {
     SC_COST_X = 0,                                    // this rank's cost at the linearisation point
     SC_CAND_COST = 1, SC_MCC_PTS = 2, SC_STEP2_PTS = 3, SC_X2_PTS = 4, SC_GDOT_PTS = 5,  // summed over ranks
     SC_GMAX_PTS = 6,                                  // max over ranks; slots 2..6 are written as one group by sum5
-    // slot 7 is unused
+    SC_STOP = 7,                                      // max over ranks (with SC_GMAX_PTS): a rank's vote to end the solve (time limit)
     SC_MCC_CAM = 8, SC_STEP2_CAM = 9, SC_X2_CAM = 10, SC_GDOT_CAM = 11, SC_GMAX_CAM = 12,  // replicated
     SC_LIN_ITERS = 13, SC_LIN_RESID = 14, SC_LIN_STATUS = 15,
     SC_SCHUR_STATUS = 16,                             // rank-local; spread through the candidate cost (launch_status_poison);
@@ -111,10 +111,15 @@ void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clea
 // last one a max), out_cam5 the same of the camera-update partials, out_cost = 0.5 sum cost_part; host_dst != NULL: then the publication (see launch_publish)
 // gate != NULL: *gate = the LM acceptance test (status words all zero, finite positive model change, (x_cost - candidate
 // cost) / model change > min_relative_decrease) if gate_enabled, else 0 - for launches enqueued behind this one
+// stop_vote: this rank's vote to end the solve, written to out5[5] (SC_STOP follows the five step scalars)
 void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cam5, uint32_t n_cam5, double* out_cam5,
                       const double* cost_part, uint32_t n_cost, double* out_cost, double* gate, const double* status, double x_cost,
-                      double min_relative_decrease, int gate_enabled, double* pub_src, int n_pub, int clear_first, int clear_n,
-                      double* host_dst, unsigned long long* host_seq, unsigned long long seq);
+                      double min_relative_decrease, int gate_enabled, double stop_vote, double* pub_src, int n_pub, int clear_first,
+                      int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq);
+// Multi-rank jobs: the acceptance test and the publication AFTER the step scalars were summed over the ranks - the same
+// test on the same operands as launch_step_sums applies on one rank, read from the scalar slots (scal = the SC_* array)
+void launch_gate_publish(hipStream_t s, double* scal, double x_cost, double min_relative_decrease, int gate_enabled, double* pub_src,
+                         int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq);
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
@@ -135,6 +140,10 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
 // Multi-rank jobs: a rank whose point elimination failed (SC_SCHUR_STATUS) turns its share of the candidate cost
 // into +inf before the scalars are summed, so every rank sees a non-finite candidate and rejects the step alike.
 void launch_status_poison(hipStream_t s, double* scal);
+// dst[i] = src[i], i < n; either side may be pinned host memory mapped into the device (host-collective staging)
+void launch_copy_f64(hipStream_t s, double* dst, const double* src, uint64_t n);
+// *host_seq = seq (pinned host memory) after everything enqueued before it has completed
+void launch_flag(hipStream_t s, unsigned long long* host_seq, unsigned long long seq);
 
 // long-track points (see LongPoint): damped point block inverse, W / Y of every free-camera observation into
 // wy[lo][36] and Y g into the slab at lo_cam_off[lo]; then Y_a W_b^T of every listed pair into the slab at pair_off

@@ -174,7 +174,9 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
 }
 
 // Read-back for the parity tests only: the loss-corrected residual and the full Jacobian blocks of every observation,
-// exactly as ba_linearize forms them in registers before it folds them into the compact row.
+// formed from the SAME function ba_linearize calls (residual_ad: r, A, D) - J_p = A R, J_c = [A D | A] - so the blocks the
+// tests compare are those the shipped kernel folds into the compact row.  (The stored rows themselves are read back
+// through SOSLAM_DBG_COMPACT_ROWS.)
 __global__ __launch_bounds__(kTileThreads) void ba_debug_rows_kernel(
     const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
     const double* __restrict__ campre, const double* __restrict__ pts, const int32_t* __restrict__ cam_free,
@@ -188,11 +190,17 @@ __global__ __launch_bounds__(kTileThreads) void ba_debug_rows_kernel(
         const size_t k = (size_t)t.start + o;
         const uint32_t p = obs_pt[k];
         const double x[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
-        double r[4], jc[24], jp[12];
-        (void)residual_jacobian(pr, x, uv[k], P, delta, fixed, r, jc, jp);
-        for (int i = 0; i < 4; i++) r_out[4 * k + i] = r[i];
-        for (int i = 0; i < 24; i++) jc_out[24 * k + i] = jc[i];
-        for (int i = 0; i < 12; i++) jp_out[12 * k + i] = jp[i];
+        double r[4], am[12], D[9];
+        (void)residual_ad(pr, x, uv[k], P, delta, r, am, D);
+        for (int i = 0; i < 4; i++) {
+            r_out[4 * k + i] = r[i];
+            const double a0 = am[i * 3], a1 = am[i * 3 + 1], a2 = am[i * 3 + 2];
+            for (int j = 0; j < 3; j++) {
+                jc_out[24 * k + i * 6 + j] = fixed ? 0.0 : a0 * D[j] + a1 * D[3 + j] + a2 * D[6 + j];
+                jc_out[24 * k + i * 6 + 3 + j] = fixed ? 0.0 : am[i * 3 + j];
+                jp_out[12 * k + i * 3 + j] = a0 * pr.R[j] + a1 * pr.R[3 + j] + a2 * pr.R[6 + j];
+            }
+        }
     }
 }
 
@@ -300,7 +308,8 @@ __global__ __launch_bounds__(1024) void sum5_kernel(const double* __restrict__ i
 __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __restrict__ part5, uint32_t n5, double* __restrict__ out5,
                                                              const double* __restrict__ cam5, uint32_t n_cam5, double* __restrict__ out_cam5,
                                                              const double* __restrict__ cost_part, uint32_t n_cost,
-                                                             double* __restrict__ out_cost, const StepGate sg, const Publish pb)
+                                                             double* __restrict__ out_cost, const StepGate sg, const double stop_vote,
+                                                             const Publish pb)
 {
     __shared__ double red[16 * 11];
     __shared__ double fin[11];
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __rest
         if (k < 5) out5[k] = a;
         else if (k == 5) out_cost[0] = a;
         else out_cam5[k - 6] = a;
+        if (k == 0) out5[5] = stop_vote;   // SC_STOP
     }
     if (sg.gate) {
         // The LM loop's acceptance test, on the device: the host has already enqueued the linearisation at the candidate
@@ -347,6 +357,18 @@ __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __rest
             const bool ok = sg.status[2] == 0.0 && sg.status[3] == 0.0 && isfinite(mcc) && isfinite(cand) && mcc > 0.0;
             *sg.gate = (sg.enabled && ok && (sg.x_cost - cand) / mcc > sg.min_relative_decrease) ? 1.0 : 0.0;
         }
+    }
+    publish_tail(pb);
+}
+
+// The acceptance test on scalars that were summed over the ranks after ba_step_sums wrote them, then the publication.
+__global__ __launch_bounds__(64) void ba_gate_publish_kernel(double* __restrict__ scal, const double x_cost,
+                                                              const double min_relative_decrease, const int enabled, const Publish pb)
+{
+    if (threadIdx.x == 0) {
+        const double mcc = scal[SC_MCC_PTS] + scal[SC_MCC_CAM], cand = scal[SC_CAND_COST];
+        const bool ok = scal[SC_LIN_STATUS] == 0.0 && scal[SC_SCHUR_STATUS] == 0.0 && isfinite(mcc) && isfinite(cand) && mcc > 0.0;
+        scal[SC_GATE] = (enabled && ok && (x_cost - cand) / mcc > min_relative_decrease) ? 1.0 : 0.0;
     }
     publish_tail(pb);
 }
@@ -1103,11 +1125,18 @@ void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clea
 
 void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cam5, uint32_t n_cam5, double* out_cam5,
                       const double* cost_part, uint32_t n_cost, double* out_cost, double* gate, const double* status, double x_cost,
-                      double min_relative_decrease, int gate_enabled, double* pub_src, int n_pub, int clear_first, int clear_n,
-                      double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+                      double min_relative_decrease, int gate_enabled, double stop_vote, double* pub_src, int n_pub, int clear_first,
+                      int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq)
 {
     hipLaunchKernelGGL(ba_step_sums_kernel, dim3(1), dim3(1024), 0, s, part5, n5, out5, cam5, n_cam5, out_cam5, cost_part, n_cost, out_cost,
-                       StepGate{gate, status, x_cost, min_relative_decrease, gate_enabled},
+                       StepGate{gate, status, x_cost, min_relative_decrease, gate_enabled}, stop_vote,
+                       Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
+}
+
+void launch_gate_publish(hipStream_t s, double* scal, double x_cost, double min_relative_decrease, int gate_enabled, double* pub_src,
+                         int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+{
+    hipLaunchKernelGGL(ba_gate_publish_kernel, dim3(1), dim3(64), 0, s, scal, x_cost, min_relative_decrease, gate_enabled,
                        Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
 }
 
@@ -1155,6 +1184,32 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
         hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(schur_threads(32)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
                            q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
     }
+}
+
+// Staging of the host-collective leg: device <-> pinned host memory by a kernel, in stream order with everything else
+// (the same mechanism as the publication of the step scalars; no copy engine, no second queue).
+__global__ __launch_bounds__(256) void ba_copy_f64_kernel(double* __restrict__ dst, const double* __restrict__ src, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+void launch_copy_f64(hipStream_t s, double* dst, const double* src, uint64_t n)
+{
+    if (!n) return;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(ba_copy_f64_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, dst, src, n);
+}
+
+// a sequence number into pinned host memory once everything before it on the stream has completed and is visible to the host
+__global__ void ba_flag_kernel(unsigned long long* __restrict__ host_seq, const unsigned long long seq)
+{
+    __threadfence_system();
+    __atomic_store_n(host_seq, seq, __ATOMIC_RELEASE);
+}
+
+void launch_flag(hipStream_t s, unsigned long long* host_seq, unsigned long long seq)
+{
+    hipLaunchKernelGGL(ba_flag_kernel, dim3(1), dim3(1), 0, s, host_seq, seq);
 }
 
 __global__ void ba_status_poison_kernel(double* __restrict__ scal)

@@ -18,6 +18,7 @@
 #include "ba_kernels.h"
 #include "common.h"
 #include "linsolve.h"
+#include "rccl_leg.h"
 
 namespace soslam {
 
@@ -111,7 +112,19 @@ struct soslam_ba {
     // multi-GPU
     soslam_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
+    soslam_host_allreduce_fn host_allreduce = nullptr;   // collective on host memory: the library stages through `stage`
+    void* host_allreduce_user = nullptr;
+    double* stage = nullptr;            // pinned staging buffer of the host collective
+    uint64_t stage_count = 0;
+    unsigned long long* stage_seq = nullptr;   // behind it: sequence number of the last download
+    unsigned long long stage_seq_next = 0;
+    RcclComm* rccl = nullptr;           // the library's own RCCL communicator (soslam_ba_init_rccl); wins over the callback
     int rank = 0, world = 1;
+    // a collective is attached (the RCCL leg or a callback): the iteration takes the multi-rank path - payload and scalar
+    // all-reduces, acceptance test after them - whatever the number of ranks (a one-rank job exercises every step of it)
+    bool collective() const { return rccl != nullptr || allreduce != nullptr || host_allreduce != nullptr; }
+    bool stop_agreed = false;           // multi-rank: some rank voted to end the solve (time limit) in the last iteration
+    DevBuf<double> gather;              // soslam_ba_get_state_global: all ranks' points
 
     // trust region
     double radius = 0.0, decrease_factor = 2.0, x_cost = 0.0;
@@ -138,6 +151,8 @@ struct soslam_ba {
     {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         if (host_raw) (void)hipHostFree(host_raw);
+        if (stage) (void)hipHostFree(stage);
+        rccl_comm_destroy(rccl);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -693,9 +708,69 @@ int linearize(soslam_ba* h)
     return SOSLAM_OK;
 }
 
+// spin on a sequence number in pinned host memory that a kernel on the handle's stream writes
+int wait_host_seq(soslam_ba* h, const unsigned long long* word, unsigned long long seq)
+{
+    SOSLAM_HIP_CHECK(hipGetLastError());
+    uint64_t spins = 0;
+    while (__atomic_load_n(word, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xFFFF) == 0) {   // a failed launch or a dead device must not spin forever
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q != hipErrorNotReady && q != hipSuccess) SOSLAM_HIP_CHECK(q);
+            if (q == hipSuccess && __atomic_load_n(word, __ATOMIC_ACQUIRE) != seq) {
+                set_last_error("a sequence number published by the device did not arrive");
+                return SOSLAM_ERR_HIP;
+            }
+        }
+    }
+    return SOSLAM_OK;
+}
+
+// pinned, host-coherent staging memory of the host-collective leg (+ its sequence word)
+int stage_reserve(soslam_ba* h, uint64_t count)
+{
+    if (h->stage_count >= count) return SOSLAM_OK;
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->stage) (void)hipHostFree(h->stage);
+    h->stage = nullptr; h->stage_count = 0;
+    // one allocation: [count f64 | sequence word]; coherent (uncached on the device): the device reads what the host wrote
+    SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->stage), sizeof(double) * (count + 1), hipHostMallocCoherent | hipHostMallocMapped));
+    h->stage_count = count;
+    h->stage_seq = reinterpret_cast<unsigned long long*>(h->stage + count);
+    *h->stage_seq = 0;
+    h->stage_seq_next = 0;
+    return SOSLAM_OK;
+}
+
 int do_allreduce(soslam_ba* h, double* buf, uint64_t count, int op)
 {
-    if (h->world <= 1 || !h->allreduce) return SOSLAM_OK;
+    // the library's own RCCL leg: in place, on the handle's stream - ordered against its kernels by construction
+    if (h->rccl) return rccl_allreduce_f64(h->rccl, buf, count, op, h->stream);
+    if (h->host_allreduce) {
+        // host collective (MPI without device support, gloo): the library stages the range through its own pinned buffer on
+        // its own stream - device -> host, the caller's in-place reduction of the host range, host -> device.  Both
+        // directions are kernels on the handle's stream (pinned memory is mapped into the device) and the host learns of
+        // the download by polling a sequence number a kernel writes behind it - the mechanism of the step-scalar
+        // publication: no copy engine, no second queue, no stream-synchronisation call inside an iteration.
+        SOSLAM_CHECK(stage_reserve(h, count));
+        double* stage_dev = nullptr;
+        unsigned long long* seq_dev = nullptr;
+        SOSLAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&stage_dev), h->stage, 0));
+        SOSLAM_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&seq_dev), h->stage_seq, 0));
+        launch_copy_f64(h->stream, stage_dev, buf, count);
+        const unsigned long long seq = ++h->stage_seq_next;
+        launch_flag(h->stream, seq_dev, seq);
+        SOSLAM_CHECK(wait_host_seq(h, h->stage_seq, seq));
+        if (h->host_allreduce(h->host_allreduce_user, h->stage, count, op) != 0) {
+            set_last_error("host all-reduce callback failed (rank %d, %llu f64)", h->rank, (unsigned long long)count);
+            return SOSLAM_ERR_COMM;
+        }
+        // the upload is ordered before every later kernel by the stream, and before the next download into the staging
+        // buffer likewise: the host never has to wait for it
+        launch_copy_f64(h->stream, buf, stage_dev, count);
+        return SOSLAM_OK;
+    }
+    if (!h->allreduce) return SOSLAM_OK;
     if (h->allreduce(h->allreduce_user, buf, count, op, h->stream) != 0) {
         set_last_error("all-reduce callback failed (rank %d, %llu f64)", h->rank, (unsigned long long)count);
         return SOSLAM_ERR_COMM;
@@ -722,7 +797,7 @@ void run_schur(soslam_ba* h, const LmDiag& lm)
 constexpr uint32_t kPcgMultiMinRows = 64;   // below this one workgroup does a whole PCG iteration faster than three launches
 
 // one trust-region step from the current linearisation: reduced system, solve, candidate, candidate cost
-int take_step(soslam_ba* h, double radius, bool speculate = false)
+int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vote = false)
 {
     hipStream_t s = h->stream;
     unsigned long long published = 0;   // sequence number if the scalars were already handed to the host
@@ -811,16 +886,32 @@ int take_step(soslam_ba* h, double radius, bool speculate = false)
                     h->opt.huber_delta, h->cost_part.p);
         // one launch for the back-substitution's step scalars and the candidate cost; on a single rank nothing follows
         // it, so it also hands the iteration's scalars to the host
-        if (h->world <= 1) published = ++h->publish_seq;
-        // speculation (single rank, cost at x known): the kernel decides acceptance itself and the linearisation at the
-        // candidate is enqueued right behind it, gated by that decision - the GPU does not wait for the host's round trip
-        const bool spec = speculate && h->world <= 1 && h->x_cost_known;
+        if (!h->collective()) published = ++h->publish_seq;
+        // speculation (cost at x known): the acceptance test runs on the device and the linearisation at the candidate is
+        // enqueued right behind it, gated by that decision - the GPU does not wait for the host's round trip.  On one rank
+        // the sum kernel decides; in a multi-rank job the same test runs after the scalars were summed (ba_gate_publish)
+        const bool spec = speculate && h->x_cost_known;
         static_assert(SC_LIN_STATUS == SC_LIN_ITERS + 2 && SC_SCHUR_STATUS == SC_LIN_ITERS + 3, "status words as StepGate reads them");
+        static_assert(SC_STOP == SC_MCC_PTS + 5 && SC_STOP == SC_GMAX_PTS + 1, "the stop vote follows the five step scalars");
         launch_step_sums(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS, h->cam_part.p, cam_update_blocks(h->n_cam),
                          h->scalp() + SC_MCC_CAM, h->cost_part.p, h->n_tiles, h->scalp() + SC_CAND_COST, h->scalp() + SC_GATE,
-                         h->scalp() + SC_LIN_ITERS, h->x_cost, h->opt.min_relative_decrease, spec ? 1 : 0, h->tail(), 4 + SC_COUNT,
-                         4 + SC_LIN_ITERS, 4, published ? h->host_raw : nullptr, h->host_seq, published);
+                         h->scalp() + SC_LIN_ITERS, h->x_cost, h->opt.min_relative_decrease, (spec && !h->collective()) ? 1 : 0,
+                         stop_vote ? 1.0 : 0.0, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, published ? h->host_raw : nullptr, h->host_seq,
+                         published);
         speculated = spec;
+    }
+    static_assert(4 + SC_COUNT <= 64, "one wave publishes the scalars");
+    if (h->collective()) {
+        StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
+        // a rank whose point elimination failed turns its share of the candidate cost into +inf: every rank rejects alike
+        launch_status_poison(s, h->scalp());
+        SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_CAND_COST, 5, SOSLAM_REDUCE_SUM));
+        // the largest point gradient and the ranks' votes to stop (time limit): one MAX, only when termination is tested
+        if (h->opt.check_termination) SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_GMAX_PTS, 2, SOSLAM_REDUCE_MAX));
+        // acceptance test on the summed scalars (identical on every rank), then the publication
+        published = ++h->publish_seq;
+        launch_gate_publish(s, h->scalp(), h->x_cost, h->opt.min_relative_decrease, speculated ? 1 : 0, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS,
+                            4, h->host_raw, h->host_seq, published);
     }
     if (speculated) {
         const double* gate = h->scalp() + SC_GATE;
@@ -836,34 +927,11 @@ int take_step(soslam_ba* h, double radius, bool speculate = false)
         }
     }
     {
-        StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
-        if (h->world > 1) launch_status_poison(s, h->scalp());
-        SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_CAND_COST, 5, SOSLAM_REDUCE_SUM));
-        if (h->opt.check_termination) SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_GMAX_PTS, 1, SOSLAM_REDUCE_MAX));
-    }
-    {
         StageScope sc(h, SOSLAM_STAGE_SYNC);
         // the tail (this iteration's cost at the linearisation point, summed over ranks) lies right in front of the scalars
         // a kernel writes them into pinned host memory and then a sequence number the host polls: no copy command,
         // no completion signal between the GPU's last store and the host's decision
-        static_assert(4 + SC_COUNT <= 64, "one wave publishes the scalars");
-        unsigned long long seq = published;
-        if (!seq) {
-            seq = ++h->publish_seq;
-            launch_publish(s, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, h->host_raw, h->host_seq, seq);
-        }
-        SOSLAM_HIP_CHECK(hipGetLastError());
-        uint64_t spins = 0;
-        while (__atomic_load_n(h->host_seq, __ATOMIC_ACQUIRE) != seq) {
-            if ((++spins & 0xFFFF) == 0) {   // a failed launch or a dead device must not spin forever
-                const hipError_t q = hipStreamQuery(s);
-                if (q != hipErrorNotReady && q != hipSuccess) SOSLAM_HIP_CHECK(q);
-                if (q == hipSuccess && __atomic_load_n(h->host_seq, __ATOMIC_ACQUIRE) != seq) {
-                    set_last_error("scalar publication did not arrive");
-                    return SOSLAM_ERR_HIP;
-                }
-            }
-        }
+        SOSLAM_CHECK(wait_host_seq(h, h->host_seq, published));
     }
     SOSLAM_HIP_CHECK(hipGetLastError());
     // The band factor is exact, so one PCG round (= a direct solve plus the true residual) normally meets the
@@ -916,6 +984,7 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
     sum.termination = SOSLAM_TERM_MAX_ITERATIONS;
     const double t0 = now_sec();
     h->log.clear();
+    h->stop_agreed = false;
     hipStream_t s = h->stream;
 
     if (!h->linearized) SOSLAM_CHECK(linearize(h));
@@ -927,11 +996,21 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
     while (true) {
         if (it >= max_it) { sum.termination = SOSLAM_TERM_MAX_ITERATIONS; break; }
         if (check && h->radius < o.min_radius) { sum.termination = SOSLAM_TERM_MIN_RADIUS; break; }
-        if (check && o.max_solver_time_seconds > 0.0 && now_sec() - t0 > o.max_solver_time_seconds) { sum.termination = SOSLAM_TERM_TIME; break; }
+        // The wall-clock test (/root/reference/src/params.h:41 through bundle_adjuster.cpp:18) reads this rank's clock.  On one
+        // rank it ends the loop here, as Ceres does at the top of an iteration.  In a multi-rank job a rank-local exit
+        // would leave the other ranks waiting in the next all-reduce, so the rank VOTES: the vote travels with this
+        // iteration's MAX all-reduce and every rank leaves together at the top of the next one.
+        bool stop_vote = false;
+        if (check && o.max_solver_time_seconds > 0.0 && now_sec() - t0 > o.max_solver_time_seconds) {
+            if (!h->collective()) { sum.termination = SOSLAM_TERM_TIME; break; }
+            stop_vote = true;
+        }
+        if (h->stop_agreed) { h->stop_agreed = false; sum.termination = SOSLAM_TERM_TIME; break; }
         if (!h->linearized) SOSLAM_CHECK(linearize(h));   // only after a speculative linearisation the host did not follow
         const double radius = h->radius;
-        SOSLAM_CHECK(take_step(h, radius, true));
+        SOSLAM_CHECK(take_step(h, radius, true, stop_vote));
         StepScalars sc = read_scalars(h);
+        if (check && h->collective() && h->host_scal[SC_STOP] != 0.0) h->stop_agreed = true;
         // the device accepted the step and has already linearised at the candidate (speculation, see take_step); if the
         // host ends up keeping x after all, the linearisation at x has to be made again
         bool dev_linearized = h->host_scal[SC_GATE] != 0.0;
@@ -967,9 +1046,13 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
             e.valid = 0;
             h->log.push_back(e);
             if (check && ++h->invalid_run >= 5) { sum.termination = SOSLAM_TERM_INVALID_STEPS; break; }
-            h->radius /= h->decrease_factor;
-            h->decrease_factor *= 2.0;
-            if (o.verbose) printf("%4d  cost %.9e  invalid step (model change %.3e)  radius %.3e\n", it, sc.x_cost, sc.mcc, radius);
+            // Ceres: TrustRegionMinimizer::HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid halves the radius
+            // and leaves the rejected-step factor alone (a later rejection still divides by the factor it would have used)
+            h->radius *= 0.5;
+            if (o.verbose)
+                printf("[rank %d] %4d  cost %.9e  invalid step (model change %.3e, candidate %.9e, solver status %d, elimination status %d, lin_it %d, "
+                       "lin_res %.2e)  radius %.3e\n", h->rank, it, sc.x_cost, sc.mcc, sc.cand_cost, sc.lin_status, sc.schur_status, sc.lin_iters,
+                       h->host_scal[SC_LIN_RESID], radius);
             continue;
         }
         h->invalid_run = 0;
@@ -1017,7 +1100,7 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         }
         h->log.push_back(e);
         if (o.verbose)
-            printf("%4d  cost %.9e  cand %.9e  model %.3e  rho %.3e  |step| %.3e  radius %.3e  lin_it %d  lin_res %.2e  %s\n", it, sc.x_cost,
+            printf("[rank %d] %4d  cost %.9e  cand %.9e  model %.3e  rho %.3e  |step| %.3e  radius %.3e  lin_it %d  lin_res %.2e  %s\n", h->rank, it, sc.x_cost,
                    sc.cand_cost, sc.mcc, rel, sc.step_norm, radius, sc.lin_iters, h->host_scal[SC_LIN_RESID], e.accepted ? "accepted" : "rejected");
     }
     SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
@@ -1247,6 +1330,57 @@ int soslam_ba_set_allreduce(soslam_ba* h, soslam_allreduce_fn fn, void* user, in
     return SOSLAM_OK;
 }
 
+int soslam_ba_set_host_allreduce(soslam_ba* h, soslam_host_allreduce_fn fn, void* user, int32_t rank, int32_t world)
+{
+    if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return SOSLAM_ERR_INVALID_ARGUMENT;
+    h->host_allreduce = fn; h->host_allreduce_user = user; h->rank = rank; h->world = world;
+    h->linearized = false; h->x_cost_known = false;
+    return SOSLAM_OK;
+}
+
+int soslam_rccl_get_unique_id(void* id128)
+{
+    if (!id128) return SOSLAM_ERR_INVALID_ARGUMENT;
+    return rccl_get_unique_id(id128);
+}
+
+int soslam_ba_init_rccl(soslam_ba* h, const void* id128, int32_t rank, int32_t world)
+{
+    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (h->stream) SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    rccl_comm_destroy(h->rccl);
+    h->rccl = nullptr;
+    SOSLAM_CHECK(rccl_comm_create(id128, rank, world, h->device, &h->rccl));
+    h->rank = rank; h->world = world;
+    h->linearized = false; h->x_cost_known = false;   // sums over a different set of ranks from now on
+    return SOSLAM_OK;
+}
+
+int soslam_ba_get_state_global(soslam_ba* h, double* poses, uint32_t n_pt_global, uint32_t shard_begin, double* points_global)
+{
+    if (!h || !points_global) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (!h->have_state) { set_last_error("get_state_global before set_state"); return SOSLAM_ERR_STATE; }
+    if ((uint64_t)shard_begin + h->n_pt > n_pt_global) {
+        set_last_error("shard [%u, %u) does not fit %u points", shard_begin, shard_begin + h->n_pt, n_pt_global);
+        return SOSLAM_ERR_INVALID_ARGUMENT;
+    }
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    // own points in the caller's order at their global place, zero elsewhere; the sum over ranks is the whole map
+    std::vector<double> own((size_t)h->n_pt * 3), p((size_t)h->n_pt * 3);
+    if (h->n_pt) SOSLAM_HIP_CHECK(hipMemcpyAsync(p.data(), h->pts[h->cur].p, sizeof(double) * p.size(), hipMemcpyDeviceToHost, s));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < h->n_pt; i++) std::memcpy(&own[3 * (size_t)h->pt_int2user[i]], &p[3 * (size_t)i], 3 * sizeof(double));
+    SOSLAM_CHECK(h->gather.alloc((size_t)n_pt_global * 3));
+    SOSLAM_CHECK(h->gather.zero(s));
+    if (h->n_pt) SOSLAM_HIP_CHECK(hipMemcpyAsync(h->gather.p + 3 * (size_t)shard_begin, own.data(), sizeof(double) * own.size(), hipMemcpyHostToDevice, s));
+    SOSLAM_CHECK(do_allreduce(h, h->gather.p, (uint64_t)n_pt_global * 3, SOSLAM_REDUCE_SUM));
+    SOSLAM_HIP_CHECK(hipMemcpyAsync(points_global, h->gather.p, sizeof(double) * 3 * (size_t)n_pt_global, hipMemcpyDeviceToHost, s));
+    if (poses) SOSLAM_HIP_CHECK(hipMemcpyAsync(poses, h->cams[h->cur].p, sizeof(double) * 6 * h->n_cam, hipMemcpyDeviceToHost, s));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return SOSLAM_OK;
+}
+
 int soslam_ba_reduce_buffer_count(soslam_ba* h, uint64_t* count)
 {
     if (!h || !count) return SOSLAM_ERR_INVALID_ARGUMENT;
@@ -1376,7 +1510,8 @@ int soslam_ba_debug_read(soslam_ba* h, int32_t what, void* dst, uint64_t bytes)
     case SOSLAM_DBG_JAC_POINT:
     case SOSLAM_DBG_JAC_CAM: {
         // the device keeps compact rows [G | h]; the blocks the tests compare are formed again by a read-back kernel
-        // with the arithmetic of ba_linearize, at the linearisation point (pose table and points it was made from)
+        // from ba_linearize's own per-observation function (residual_ad), at the linearisation point (pose table and
+        // points it was made from); the stored rows are checked against them through SOSLAM_DBG_COMPACT_ROWS
         const size_t w = what == SOSLAM_DBG_RESIDUALS ? 4 : (what == SOSLAM_DBG_JAC_POINT ? 12 : 24);
         SOSLAM_CHECK(need(n_obs * w * sizeof(double)));
         DevBuf<double> dr, djc, djp;
@@ -1388,6 +1523,16 @@ int soslam_ba_debug_read(soslam_ba* h, int32_t what, void* dst, uint64_t bytes)
         SOSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
         SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
         for (size_t i = 0; i < n_obs; i++) std::memcpy(out + w * h->obs_int2user[i], &tmp[i * w], w * sizeof(double));
+        return SOSLAM_OK;
+    }
+    case SOSLAM_DBG_COMPACT_ROWS: {
+        // the stored rows themselves (whatever the production linearisation left in `ar`), not a recomputation
+        SOSLAM_CHECK(need(n_obs * 9 * sizeof(double)));
+        if (!h->linearized) { set_last_error("debug_read(COMPACT_ROWS): no linearisation held"); return SOSLAM_ERR_STATE; }
+        std::vector<double> tmp(n_obs * kArRow);
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->ar.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < n_obs; i++) std::memcpy(out + 9 * (size_t)h->obs_int2user[i], &tmp[i * kArRow], 9 * sizeof(double));
         return SOSLAM_OK;
     }
     case SOSLAM_DBG_COST:

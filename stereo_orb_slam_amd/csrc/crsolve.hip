@@ -10,7 +10,7 @@
 //                                                   of the f64 matrix cores, one workgroup per node)
 //   cr_reduce : per remaining k with a = k-h, c = k+h (f64 matrix cores, one workgroup per 16 columns of the node)
 //                 Q_a = E_a F_k^T        P_c = E_c F_c
-//                 D_k -= F_k Q_a + F_c^T P_c        F_k <- -Q_a^T F_a      (fill: A(k, k-2h))
+//                 D_k -= F_k Q_a + F_c^T P_c        F_k <- -Q_a^T F_a      (fill: A(k, k-2h), written to the other coupling array)
 // Each product is owned by exactly one remaining node.  With the explicit inverse every step of a later solve is a
 // matrix-vector product:   forward   w_k -= Q_a^T w_a + P_c^T w_c      backward   x_i = E_i w_i - P_i x_{i-h} - Q_i x_{i+h}
 // i.e. one small launch per level and sweep - two levels per launch with cr_fwd2 / cr_bwd2 / cr_top2 (ceil(log2 m) - 1
@@ -18,6 +18,9 @@
 // order: bitwise reproducible.  Positive definiteness is inherited by every Schur complement, so the sweep needs no
 // pivoting; a non-positive 3x3 pivot block raises scal[SC_LIN_STATUS].
 #include "linsolve.h"
+
+#include <algorithm>
+#include <cstdlib>
 
 #include "ba_kernels.h"
 
@@ -48,7 +51,8 @@ __device__ __forceinline__ double4_t mfma_ptq_tile(const double* __restrict__ P,
 struct CrView {
     uint32_t m;       // super-blocks
     int bw, sb;       // cameras per super-block, scalars per super-block
-    double *D, *F, *E, *P, *Q, *PT, *QT;   // each [m][sb*sb], row-major; P, Q (and transposes) indexed by the eliminated node
+    double *D, *F, *E, *P, *Q, *PT, *QT, *F2;   // each [m][sb*sb], row-major; P, Q (and transposes) indexed by the eliminated node;
+                                                // F2: the couplings of the next level (cr_reduce reads one of F / F2 and writes the other)
 };
 
 // gather the upper block-sparse S into D (diagonal super-blocks) and F (F_i = A(i, i-1)) through a host-built map
@@ -246,9 +250,20 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, double* __restri
     }
 }
 
-__global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrView v, const uint32_t h)
+// The fill F_k <- -Q_a^T F_a goes to Fout, NOT over F_k: the column-tile workgroups of a node all read the whole of the
+// old F_k, and nothing orders one workgroup's stores against another's loads inside a launch (on a busy or shared device
+// they start at different times - a workgroup arriving late would stage rows a sibling has already replaced).
+__global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrView v, const uint32_t h, const double* __restrict__ Fin,
+                                                                     double* __restrict__ Fout, const uint32_t stagger_10ns)
 {
     extern __shared__ double lds[];
+    // Test hook (SOSLAM_CR_STAGGER, tests/test_ba_gpu.py::test_cyclic_reduction_tiles_do_not_race): the first column tile of
+    // every node starts late by the given time, as it may on a busy or shared device, so that any dependence of one
+    // workgroup of this launch on the loads of another shows every time instead of once in a while.  Bounded wait.
+    if (stagger_10ns && blockIdx.y == 0) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        while (__builtin_amdgcn_s_memrealtime() - t0 < stagger_10ns) __builtin_amdgcn_s_sleep(16);
+    }
     const int sb = v.sb, tid = threadIdx.x;
     const size_t sb2 = (size_t)sb * sb;
     const uint32_t k = 2 * h * blockIdx.x;
@@ -270,10 +285,10 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
 
     StageRegs rEa, rFk, rFa, rEc, rFc;
     stage_load(rEa, v.E + a * sb2, sb, wave, lane, has_a);
-    stage_load(rFk, v.F + k * sb2, sb, wave, lane, has_a);
-    stage_load(rFa, v.F + a * sb2, sb, wave, lane, fill);
+    stage_load(rFk, Fin + k * sb2, sb, wave, lane, has_a);
+    stage_load(rFa, Fin + a * sb2, sb, wave, lane, fill);
     stage_load(rEc, v.E + c * sb2, sb, wave, lane, has_c);
-    stage_load(rFc, v.F + c * sb2, sb, wave, lane, has_c);
+    stage_load(rFc, Fin + c * sb2, sb, wave, lane, has_c);
     double dk[4];   // this wave's tile of D_k
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
         if (active) {
             dacc = mfma_ptq_tile(B1, B2, kp, w0, q0, lane);                                   // (F_k Q_a)[w, q]
             // rows q of the fill: -(Q_a[:, q])^T F_a, this wave takes column tile w
-            if (fill) put(mfma_ptq_tile(B2, B3, kp, q0, w0, lane), q0, w0, v.F + k * sb2, nullptr, nullptr, -1.0);
+            if (fill) put(mfma_ptq_tile(B2, B3, kp, q0, w0, lane), q0, w0, Fout + k * sb2, nullptr, nullptr, -1.0);
         }
         __syncthreads();
     }
@@ -736,7 +751,7 @@ __global__ __launch_bounds__(kCrSolveThreads) void cr_top2_kernel(const CrView v
     }
 }
 
-constexpr int kCrMats = 7;
+constexpr int kCrMats = 8;
 
 CrView make_view(uint32_t n_rows, int bw, double* ws)
 {
@@ -745,6 +760,7 @@ CrView make_view(uint32_t n_rows, int bw, double* ws)
     v.m = (n_rows + (uint32_t)bw - 1) / (uint32_t)bw;
     const size_t per = (size_t)v.m * v.sb * v.sb;
     v.D = ws; v.F = ws + per; v.E = ws + 2 * per; v.P = ws + 3 * per; v.Q = ws + 4 * per; v.PT = ws + 5 * per; v.QT = ws + 6 * per;
+    v.F2 = ws + 7 * per;
     return v;
 }
 
@@ -756,7 +772,7 @@ uint32_t count_even(uint32_t m, uint32_t h) { return (m + 2 * h - 1) / (2 * h); 
 size_t cr_count(uint32_t n_rows, int bw)
 {
     const size_t m = (n_rows + (size_t)bw - 1) / (size_t)bw, sb = 6 * (size_t)bw;
-    return kCrMats * m * sb * sb + 3 * m * sb + 64;   // D F E P Q PT QT + two padded right-hand-side buffers and the solution
+    return kCrMats * m * sb * sb + 3 * m * sb + 64;   // D F E P Q PT QT F2 + two padded right-hand-side buffers and the solution
 }
 
 size_t cr_map_count(uint32_t n_rows, int bw)
@@ -795,9 +811,14 @@ void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int b
     const size_t lds_r = sizeof(double) * 4 * kp * kLd;
     if (lds_r > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
     const uint32_t nt = ((uint32_t)v.sb + 15) / 16;
+    const char* stg = std::getenv("SOSLAM_CR_STAGGER");      // test hook, see cr_reduce_kernel; at most 1 ms
+    const uint32_t stagger = stg ? (uint32_t)std::min<long>(std::max<long>(std::atol(stg), 0), 100000) : 0u;
+    const double* fin = v.F;     // the gather's couplings; each level reads one coupling array and writes the other
+    double* fout = v.F2;
     for (uint32_t h = 1; h < v.m; h *= 2) {
         launch_cr_invert(s, count_odd(v.m, h), v, h, 0, scal);
-        hipLaunchKernelGGL(cr_reduce_kernel, dim3(count_even(v.m, h), nt), dim3(kCrReduceThreads), lds_r, s, v, h);
+        hipLaunchKernelGGL(cr_reduce_kernel, dim3(count_even(v.m, h), nt), dim3(kCrReduceThreads), lds_r, s, v, h, fin, fout, stagger);
+        double* t = const_cast<double*>(fin); fin = fout; fout = t;
     }
     launch_cr_invert(s, 1, v, 0u, 1, scal);
 }

@@ -27,9 +27,9 @@ class TorchAllReduce:
         self.base = tensor.data_ptr()
         self.count = tensor.numel()
         self.group = group
-        self.host_staged = False   # set by attach() for backends that stage device tensors through the host (gloo)
         self.calls = 0
         self.elements = 0
+        self.stream_checks = []    # per call: the stream the library passed was torch's current stream during the collective
 
     def __call__(self, ptr: int, count: int, op: int, stream: int) -> int:
         import torch.distributed as dist
@@ -46,16 +46,8 @@ class TorchAllReduce:
             dev = self.tensor.device
             lib_stream = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
             with torch.cuda.stream(lib_stream):
-                if self.host_staged:
-                    # rehearsal backends without a device path of their own (gloo): stage through the host here,
-                    # synchronously - wait for the library's kernels, reduce a host copy, copy back, wait again
-                    lib_stream.synchronize()
-                    host = view.cpu()
-                    dist.all_reduce(host, op=rop, group=self.group)
-                    view.copy_(host)
-                    torch.cuda.synchronize(dev)
-                else:
-                    dist.all_reduce(view, op=rop, group=self.group)
+                self.stream_checks.append(torch.cuda.current_stream(dev).cuda_stream == (stream or 0))
+                dist.all_reduce(view, op=rop, group=self.group)
         else:
             dist.all_reduce(view, op=rop, group=self.group)
         self.calls += 1
@@ -63,8 +55,36 @@ class TorchAllReduce:
         return 0
 
 
-def attach(handle, rank: int, world: int, device, group=None) -> TorchAllReduce:
-    """Give a loaded BundleAdjustment handle a torch-owned reduce buffer and the all-reduce callback."""
+class TorchHostAllReduce:
+    """The soslam_host_allreduce_fn of include/soslam_ba.h, backed by torch.distributed on HOST memory: the library stages
+    the range through its own pinned buffer on its own stream and hands over a host array; no torch device tensor, stream
+    or allocator takes part (backends without a device path: gloo in the tests and rehearsals)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.calls = 0
+        self.elements = 0
+        self.stream_checks = []
+
+    def __call__(self, host_array, op: int) -> int:
+        import torch.distributed as dist
+        t = torch.from_numpy(host_array)        # shares the library's staging memory
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == _lib.REDUCE_SUM else dist.ReduceOp.MAX, group=self.group)
+        self.calls += 1
+        self.elements += host_array.size
+        return 0
+
+
+def attach(handle, rank: int, world: int, device, group=None):
+    """Give a loaded BundleAdjustment handle the torch.distributed collective as its all-reduce callback.
+
+    Backend nccl (= RCCL): a torch-owned reduce buffer reduced in place on the device (TorchAllReduce).  Any other backend:
+    the host leg (TorchHostAllReduce) - the library stages the payload itself."""
+    import torch.distributed as dist
+    if dist.get_backend(group) != "nccl":
+        cb = TorchHostAllReduce(group)
+        handle.set_host_allreduce(cb, rank, world)
+        return cb
     n = handle.reduce_buffer_count()
     t = torch.zeros(n, dtype=torch.float64, device=device)
     if t.is_cuda:
@@ -73,11 +93,25 @@ def attach(handle, rank: int, world: int, device, group=None) -> TorchAllReduce:
         torch.cuda.current_stream(t.device).synchronize()
     handle.set_reduce_buffer(t.data_ptr(), n)
     cb = TorchAllReduce(t, group)
-    import torch.distributed as dist
-    cb.host_staged = t.is_cuda and dist.get_backend(group) != "nccl"
     handle.set_allreduce(cb, rank, world)
     handle._reduce_tensor = t   # keep alive as long as the handle
     return cb
+
+
+def attach_rccl(handle, rank: int, world: int, device, group=None) -> None:
+    """The library's own RCCL leg instead of the callback: rank 0 draws the unique id, torch.distributed only carries its
+    128 bytes to the other ranks (the side channel; any would do), then every rank joins soslam_ba_init_rccl.  From then
+    on no Python runs inside an LM iteration."""
+    import torch.distributed as dist
+
+    from . import ba
+    # the id travels as a tensor on whatever device the process group's backend moves (nccl: the GPU, gloo: the host)
+    carrier = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    raw = ba.rccl_unique_id() if rank == 0 else bytes(_lib.RCCL_UNIQUE_ID_BYTES)
+    t = torch.tensor(list(raw), dtype=torch.uint8, device=carrier)
+    if world > 1:
+        dist.broadcast(t, src=0, group=group)
+    handle.init_rccl(bytes(t.cpu().tolist()), rank, world)
 
 
 def load_shard(handle, full_problem, rank: int, world: int):

@@ -37,6 +37,30 @@ def _oracle_solve(oracle_lib, prob, **kw):
                             prob.proj_r, prob.cam_fixed, o)
 
 
+def _compact_rows_from_blocks(r, jc, jp, cams, obs_cam, fixed):
+    """[G | h] = [A^T A (xx xy xz yy yz zz) | A^T r] of every observation from full blocks: A is the translation part of
+    J_c (d residual / d camera-frame point); for a fixed camera (J_c = 0) A = J_p R^-1 with the rotation of the branch
+    AngleAxisRotatePoint takes (/root/reference/src/reprojection_error.h:20)."""
+    out = np.zeros((len(r), 9))
+    for k in range(len(r)):
+        if fixed[obs_cam[k]]:
+            w = cams[obs_cam[k]][:3]
+            th2 = float(w @ w)
+            K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            if th2 > np.finfo(float).eps:
+                th = np.sqrt(th2)
+                R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th2 * (K @ K)
+            else:
+                R = np.eye(3) + K
+            A = jp[k] @ np.linalg.inv(R)
+        else:
+            A = jc[k][:, 3:6]
+        G = A.T @ A
+        out[k, :6] = [G[0, 0], G[0, 1], G[0, 2], G[1, 1], G[1, 2], G[2, 2]]
+        out[k, 6:] = A.T @ r[k]
+    return out
+
+
 def test_residual_jacobian_golden(gpu, golden_dir):
     """ba_linearize against torch-autograd golden blocks, incl. zero / tiny / near-pi rotations and general 3x4
     projections.  Each case is its own 1-camera 1-point problem (the projection is per handle)."""
@@ -56,6 +80,15 @@ def test_residual_jacobian_golden(gpu, golden_dir):
             h.set_state(g["cam"][idx], g["pt"][idx])
             h.debug_step(1e4)
             r, jc, jp = h.debug_read(L.DBG_RESIDUALS), h.debug_read(L.DBG_JAC_CAM), h.debug_read(L.DBG_JAC_POINT)
+            rows = h.debug_read(L.DBG_COMPACT_ROWS)
+        # the rows the production kernel STORED (what every later kernel reads) against the autograd blocks
+        uv32 = g["uv"][idx].astype(np.float32).astype(np.float64)
+        want = _compact_rows_from_blocks(g["r"][idx] + (g["uv"][idx] - uv32), g["jc"][idx], g["jp"][idx], g["cam"][idx],
+                                         np.arange(n), np.zeros(n, np.uint8))
+        for k, i in enumerate(idx):
+            th = np.linalg.norm(g["cam"][i][:3])
+            slack = 0.0 if (th == 0 or th > 1e-3) else 1e-16 / th * 1e4
+            np.testing.assert_allclose(rows[k], want[k], rtol=1e-9, atol=(1e-10 + slack) * max(1.0, np.abs(want[k]).max()))
         for k, i in enumerate(idx):
             uv32 = g["uv"][i].astype(np.float32).astype(np.float64)   # observations are stored float32
             np.testing.assert_allclose(r[k], g["r"][i] + (g["uv"][i] - uv32), rtol=1e-12, atol=1e-9)
@@ -79,7 +112,12 @@ def test_linearize_matches_oracle(gpu, oracle_lib, prob1):
         h.debug_step(1e4)
         gr, gjc, gjp = h.debug_read(L.DBG_RESIDUALS), h.debug_read(L.DBG_JAC_CAM), h.debug_read(L.DBG_JAC_POINT)
         gcost = h.debug_read(L.DBG_COST)[0]
+        rows = h.debug_read(L.DBG_COMPACT_ROWS)
     assert gcost == pytest.approx(cost, rel=1e-12)
+    # the compact rows ba_linearize stored - the only per-observation data the rest of the iteration reads - against
+    # G = A^T A, h = A^T r formed from the oracle's blocks
+    want = _compact_rows_from_blocks(r, jc, jp, cams, prob1.obs_cam, prob1.cam_fixed)
+    np.testing.assert_allclose(rows, want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
     np.testing.assert_allclose(gr, r, rtol=1e-10, atol=1e-9)
     sc = np.abs(jc).max()
     np.testing.assert_allclose(gjc, jc, rtol=1e-9, atol=1e-12 * sc)
@@ -640,3 +678,68 @@ def test_active_point_bounds(gpu, oracle_lib, prob1):
     ocams, opts_, osum, _ = _oracle_solve(oracle_lib, q, max_iterations=12, lower_bound=-25.0, upper_bound=25.0)
     assert pts.max() <= 25.0 and pts.min() >= -25.0 and (pts == 25.0).sum() > 100
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+
+
+def _with_unobserved_camera(synth, prob):
+    """prob plus one free camera that sees nothing: with min_lm_diagonal = 0 its diagonal block of the reduced camera matrix
+    is exactly zero, so the factorisation meets a non-positive pivot and the step is INVALID (not rejected)."""
+    poses = np.concatenate([prob.poses_wc, prob.poses_wc[-1:]])
+    fixed = np.concatenate([prob.cam_fixed, np.zeros(1, np.uint8)])
+    return synth.BaProblem(poses, prob.points, prob.obs_cam, prob.obs_pt, prob.obs_uv, prob.proj_l, prob.proj_r, cam_fixed=fixed)
+
+
+@pytest.mark.parametrize("solver", [1, 2, 3])
+def test_invalid_steps_halve_the_radius(gpu, oracle_lib, prob1, solver):
+    """Ceres: TrustRegionMinimizer::HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid is radius *= 0.5 with the
+    rejected-step factor untouched (not the rejected-step rule radius /= factor, factor *= 2); five invalid steps in a row end
+    the solve.  Same sequence on the device and in the oracle."""
+    ba, synth, L = gpu
+    p = _with_unobserved_camera(synth, prob1)
+    o = oracle_lib.default_options(max_iterations=4, check_termination=0, min_lm_diagonal=0.0)
+    _, _, osum, olog = oracle_lib.solve(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, o)
+    with ba.BundleAdjustment(ba.default_options(linear_solver=solver, min_lm_diagonal=0.0)) as h:
+        h.load(p)
+        c0, p0 = h.get_state()
+        h.iterate(4)
+        log = h.iteration_log()
+        c1, p1 = h.get_state()
+        # the same handle with the default diagonal floor: the radius it continues from is r0 / 16, the step is valid
+        h.set_options(ba.default_options(linear_solver=solver))
+        h.iterate(1)
+        nxt = h.iteration_log()[-1]
+        # termination: five consecutive invalid steps
+        h.set_options(ba.default_options(linear_solver=solver, min_lm_diagonal=0.0, max_iterations=20))
+        h.set_state(c0, p0)
+        s = ba.summary_dict(h.solve())
+    r0 = 1e4
+    assert [e.valid for e in log[1:]] == [0, 0, 0, 0] and [e.valid for e in olog[1:]] == [0, 0, 0, 0]
+    assert [e.radius for e in log[1:]] == [r0, r0 / 2, r0 / 4, r0 / 8]
+    assert [e.radius for e in olog[1:]] == [r0, r0 / 2, r0 / 4, r0 / 8]
+    np.testing.assert_array_equal(c1, c0)          # an invalid step moves nothing
+    np.testing.assert_array_equal(p1, p0)
+    assert nxt.valid == 1 and nxt.radius == r0 / 16
+    assert s["iterations"] == 5 and "invalid" in s["termination_name"].lower()
+
+
+@pytest.mark.parametrize("solver", [2, 3])
+def test_cyclic_reduction_tiles_do_not_race(gpu, prob2, solver, monkeypatch):
+    """Round 1's intermittent multi-rank corruption had this cause: cr_reduce wrote the fill F_k <- -Q_a^T F_a over F_k while
+    the sibling column-tile workgroups of the same node, which all stage the whole old F_k, might not have loaded it yet -
+    nothing orders workgroups inside a launch, and on a shared (or merely busy) device they start at different times.  The
+    fill now goes to a second coupling array.  Tested once with the hazard made certain: SOSLAM_CR_STAGGER delays the
+    first column tile of every node by 50 us, far longer than its siblings need to finish; the step must not change by a
+    bit."""
+    ba, synth, L = gpu
+    out = []
+    for stagger in (None, "5000"):
+        if stagger is None:
+            monkeypatch.delenv("SOSLAM_CR_STAGGER", raising=False)
+        else:
+            monkeypatch.setenv("SOSLAM_CR_STAGGER", stagger)
+        with ba.BundleAdjustment(ba.default_options(linear_solver=solver)) as h:
+            h.load(prob2)
+            h.debug_step(1e4)
+            out.append((h.debug_read(L.DBG_STEP_CAM), h.debug_read(L.DBG_STEP_POINT), h.debug_read(L.DBG_STEP_SCALARS)))
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(out[0][0]).max() > 0

@@ -30,7 +30,7 @@ def _worker(rank, world, port, out_dir):
     try:
         import oracle
         from stereo_orb_slam_amd import _lib, synth
-        from stereo_orb_slam_amd.distributed import TorchAllReduce
+        from stereo_orb_slam_amd.distributed import TorchAllReduce, TorchHostAllReduce
 
         full = synth.generate_ba(None, n_cam=12, n_pt=600, track_mode=1, track_len=5, spacing=0.8)
         cams, pts = full.poses_cw(), full.points_f64()
@@ -65,6 +65,12 @@ def _worker(rank, world, port, out_dir):
         assert cb(buf.data_ptr() + 8 * (main + 6), 1, _lib.REDUCE_SUM, 0) == 1      # out of range -> error status
         assert cb(buf.data_ptr() + 4, 1, _lib.REDUCE_SUM, 0) == 1                   # misaligned
         assert cb.calls == 3
+
+        # 3b. the host leg (soslam_ba_set_host_allreduce): the library hands over a host range it staged itself
+        hcb = TorchHostAllReduce()
+        stage = np.array([1.0 + rank, -2.0, 10.0 * (rank + 1)])
+        assert hcb(stage[:2], _lib.REDUCE_SUM) == 0 and hcb(stage[2:], _lib.REDUCE_MAX) == 0
+        assert stage.tolist() == [1.0 + 2.0, -2.0 * world, 10.0 * world] and hcb.calls == 2
 
         # 4. reduced payload + camera damping from the REDUCED diagonal == the unsharded system
         S = buf[: n6 * n6].numpy().reshape(n6, n6).copy()

@@ -107,3 +107,20 @@ def test_structure_only_when_single_fixed_camera(oracle_lib):
     np.testing.assert_array_equal(cams, cam)
     np.testing.assert_allclose(pts, pts_true, rtol=1e-5)
     assert summ.final_cost < 1e-8
+
+
+def test_invalid_steps_halve_the_radius(oracle_lib):
+    """Ceres' HandleInvalidStep (LevenbergMarquardtStrategy::StepIsInvalid): radius *= 0.5 per invalid step, the
+    rejected-step factor untouched; five in a row end the solve.  An unobserved free camera with a zero diagonal floor
+    makes every factorisation fail."""
+    from stereo_orb_slam_amd import synth
+    p = synth.generate_ba(1)
+    poses = np.concatenate([p.poses_wc, p.poses_wc[-1:]])
+    fixed = np.concatenate([p.cam_fixed, np.zeros(1, np.uint8)])
+    q = synth.BaProblem(poses, p.points, p.obs_cam, p.obs_pt, p.obs_uv, p.proj_l, p.proj_r, cam_fixed=fixed)
+    args = (q.obs_cam, q.obs_pt, q.obs_uv, q.poses_cw(), q.points_f64(), q.proj_l, q.proj_r, q.cam_fixed)
+    _, _, _, log = oracle_lib.solve(*args, oracle_lib.default_options(max_iterations=4, check_termination=0, min_lm_diagonal=0.0))
+    assert [e.valid for e in log[1:]] == [0, 0, 0, 0]
+    assert [e.radius for e in log[1:]] == [1e4, 5e3, 2.5e3, 1.25e3]
+    _, _, s, _ = oracle_lib.solve(*args, oracle_lib.default_options(max_iterations=20, min_lm_diagonal=0.0))
+    assert s.iterations == 5 and s.termination == 5   # ORACLE_TERM_INVALID_STEPS
