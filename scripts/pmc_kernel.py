@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Mean per-launch value of every counter in a rocprofv3 --pmc counter_collection.csv for kernels matching a substring.
-usage: pmc_kernel.py <counter_collection.csv> <kernel substring>"""
+"""Mean per launch of every counter of one kernel in a rocprofv3 --pmc counter_collection.csv.
+usage: pmc_kernel.py <counter_collection.csv> <kernel name substring>"""
 import collections
 import csv
 import sys
@@ -10,5 +10,4 @@ for r in csv.DictReader(open(sys.argv[1])):
     if sys.argv[2] in r["Kernel_Name"]:
         d[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(d):
-    v = d[k]
-    print(f"{k:28s} launches {len(v):4d}  mean {sum(v) / len(v):16.1f}")
+    print(f"{k:32s} {sum(d[k]) / len(d[k]):16.0f}   ({len(d[k])} launches)")

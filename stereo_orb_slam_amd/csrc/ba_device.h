@@ -290,4 +290,31 @@ __device__ __forceinline__ bool sym3_inverse(const double* __restrict__ m, doubl
     return ok;
 }
 
+// Cholesky factor C = L L^T of a symmetric positive definite 3x3 (xx xy xz yy yz zz).  Out: mt = M = L^-T (upper
+// triangular: m00 m01 m02 m11 m12 m22) and inv = C^-1 = M M^T.  ok = false when a pivot is not positive.
+__device__ __forceinline__ bool sym3_chol_inverse(const double* __restrict__ m, double* __restrict__ mt, double* __restrict__ inv)
+{
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5];
+    const double i00 = rsqrt(a);                 // 1 / l00
+    const double l10 = b * i00, l20 = c * i00;
+    const double p1 = d - l10 * l10;
+    const double i11 = rsqrt(p1);                // 1 / l11
+    const double l21 = (e - l20 * l10) * i11;
+    const double p2 = f - l20 * l20 - l21 * l21;
+    const double i22 = rsqrt(p2);                // 1 / l22
+    const bool ok = (a > 0.0) && (p1 > 0.0) && (p2 > 0.0);
+    // L^-1 = [[i00, 0, 0], [i10, i11, 0], [i20, i21, i22]]
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    mt[0] = i00; mt[1] = i10; mt[2] = i20; mt[3] = i11; mt[4] = i21; mt[5] = i22;
+    inv[0] = i00 * i00 + i10 * i10 + i20 * i20;
+    inv[1] = i10 * i11 + i20 * i21;
+    inv[2] = i20 * i22;
+    inv[3] = i11 * i11 + i21 * i21;
+    inv[4] = i21 * i22;
+    inv[5] = i22 * i22;
+    return ok;
+}
+
 }  // namespace soslam

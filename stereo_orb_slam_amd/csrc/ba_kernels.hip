@@ -463,28 +463,33 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_scale_kernel(uint32_t n_
 
 // ---------------------------------------------------------------------------------------------------
 // K5  ba_schur: one workgroup per chunk of consecutive points whose free cameras fit a window of KMAX local
-// slots.  The window's 6 KMAX x 6 KMAX matrix  sum_p Y~_p W~_p^T  (Y~_p, W~_p the point's 6 KMAX x 3 column blocks, zero
-// rows for cameras that do not see it) is a GEMM over the concatenated point columns, and it runs on the f64 matrix
-// cores.  W~ is J_c^T J_p without the per-camera factor T = blockdiag(M^T, I) (ba_device.h): ba_schur_reduce applies T
-// once per block.  Per batch (<= 256 observations, <= PB points):
+// slots.  With the damped point block C_p = L L^T (3x3 Cholesky) and U~_p = W~_p L^-T, the window's 6 KMAX x 6 KMAX matrix
+//     sum_p W~_p C_p^-1 W~_p^T = sum_p U~_p U~_p^T
+// (U~_p the point's 6 KMAX x 3 column block, zero rows for cameras that do not see it) is a SYMMETRIC rank-k update over
+// the concatenated point columns, and it runs on the f64 matrix cores out of ONE LDS image (both MFMA operands are tile
+// rows of the same image; half the LDS of the two-image form W~ C^-1 . W~^T, so three workgroups share a CU).  W~ is
+// J_c^T J_p without the per-camera factor T = blockdiag(M^T, I) (ba_device.h): ba_schur_reduce applies T once per block.
+// Per batch (<= 128 observations, <= PB points):
 //   * all lanes fetch the G part (48 B) of the batch's compact rows from HBM as 16-byte pieces - requested a whole
 //     batch AHEAD, into registers - and park them in LDS;
-//   * one lane per point inverts the damped 3x3 block of the NEXT batch's points in registers; two lanes per
-//     observation form W~ and Y~ = W~ Cinv from G, the camera's rotation (an LDS table of the chunk's window cameras)
-//     and the point, and write them into two zero-filled LDS images laid out [point column][window row];
+//   * one lane per point factors the damped 3x3 block of the NEXT batch's points in registers (L^-T, t = L^-1 g and
+//     C^-1 = L^-T L^-1 for the back-substitution); two lanes per observation form W~ from G, the camera's rotation (an
+//     LDS table of the chunk's window cameras) and the point, and write U~ = W~ L^-T into the zero-filled LDS image laid
+//     out [point column][window row];
 //   * every wave owns a fixed set of 16x16 tiles of the window's upper triangle and accumulates
 //     v_mfma_f64_16x16x4_f64 products over the batch's columns in registers (no atomics, fixed order); lane groups
-//     add the rhs part  Y~ g  with plain FMAs.
+//     add the rhs part  U~ t = W~ C^-1 g  with plain FMAs.
 // The chunk's window goes to its own slab ([pair a <= b][6x6] then [camera][6]); ba_schur_reduce sums the slabs
 // per block in a fixed order, so the reduced camera system is bitwise reproducible.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kRawRow = 6;                        // G: the first 48 B of the compact row staged per observation
 constexpr int kRawPieces = kRawRow / 2;           // 16-byte pieces per row
-// Workgroup size by window width.  Up to 16 cameras: 256 lanes and half-size batches, so that two workgroups share a
-// CU (66 KB of LDS each) and one runs while the other waits at its barriers (measured 128 -> 118 us at config 3);
-// wider windows keep 512 lanes - their 78 accumulator tiles need the registers of eight waves.
+// Workgroup size by window width.  Up to 16 cameras: 256 lanes and batches of 128 observations, so that several
+// workgroups share a CU (40 KB of LDS each) and one runs while another waits at its barriers; wider windows keep 512
+// lanes - their 78 accumulator tiles need the registers of eight waves.
 constexpr int schur_threads(int kmax) { return kmax <= 16 ? 256 : 512; }
 constexpr int kCamTab = 10;                       // per window camera: R (9), first-order-branch flag
+constexpr int kPointVals = 15;                    // per point: J_p^T J_p (6), Jacobi scale (3), J_p^T r (3), position (3)
 
 typedef double schur_double4 __attribute__((ext_vector_type(4)));
 
@@ -492,14 +497,19 @@ template <int KMAX>
 struct SchurShape {
     static constexpr int PB = schur_batch_points(KMAX);   // points per batch
     static constexpr int ROWS = 6 * KMAX;                  // window rows
-    static constexpr int LD = ROWS + 1;                    // odd leading dimension of the images
+    // leading dimension of the image: the matrix-core operand reads take 16 consecutive doubles of 4 consecutive point
+    // columns per instruction (lanes 0-15 column k, 16-31 column k + 1 in one bank group): with LD = 16 (mod 32) doubles
+    // two consecutive columns lie exactly half the banks apart - conflict-free
+    static constexpr int LD = ((ROWS + 15) / 32) * 32 + 16;
     static constexpr int KB = 3 * PB;                      // point columns per batch (multiple of 4)
     static constexpr int NT1 = (ROWS + 15) / 16;           // 16-wide tiles per dimension
     static constexpr int NUP = NT1 * (NT1 + 1) / 2;        // tiles of the upper triangle
     static constexpr int NT = schur_threads(KMAX);         // lanes per workgroup
     static constexpr int TPW = (NUP + NT / 64 - 1) / (NT / 64);   // tiles per wave
     static constexpr size_t lds_bytes =
-        sizeof(double) * ((size_t)kBatchObs * kRawRow + 2 * (size_t)KB * LD + 2 * (PB * 6 + KB + PB * 3) + KMAX * kCamTab) + 2 * kBatchObs;
+        sizeof(double) * ((size_t)kBatchObs * kRawRow + (size_t)KB * LD + 2 * (PB * 6 + KB + PB * 3) + KMAX * kCamTab + PB * kPointVals) +
+        2 * kBatchObs;
+    static_assert(LD >= ROWS && LD % 32 == 16, "image leading dimension");
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load
@@ -512,8 +522,44 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// The window product of one batch for a wave that owns the first NA of its tile slots: KB / 4 matrix instructions per
+// tile, k outermost (the tiles are independent accumulators, their products issue back to back).
+template <int NA, int TPW, int KB, int LD>
+__device__ __forceinline__ void schur_mfma_body(const double* const (&pa)[TPW], const double* const (&pb)[TPW], schur_double4 (&acc)[TPW])
+{
+    if constexpr (TPW <= 6) {
+#pragma unroll
+        for (int k0 = 0; k0 < KB; k0 += 4) {
+            double av[NA], bv[NA];
+#pragma unroll
+            for (int j = 0; j < NA; j++) { av[j] = pa[j][k0 * LD]; bv[j] = pb[j][k0 * LD]; }
+#pragma unroll
+            for (int j = 0; j < NA; j++) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j], acc[j], 0, 0, 0);
+        }
+    } else {   // wide windows: ten tiles per wave leave no registers for an unrolled operand stream
+#pragma unroll 1
+        for (int k0 = 0; k0 < KB; k0 += 4) {
+            double av[NA], bv[NA];
+#pragma unroll
+            for (int j = 0; j < NA; j++) { av[j] = pa[j][k0 * LD]; bv[j] = pb[j][k0 * LD]; }
+#pragma unroll
+            for (int j = 0; j < NA; j++) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j], acc[j], 0, 0, 0);
+        }
+    }
+}
+
+template <int TPW, int KB, int LD, int NA = TPW>
+__device__ __forceinline__ void schur_mfma_dispatch(int n_act, const double* const (&pa)[TPW], const double* const (&pb)[TPW],
+                                                    schur_double4 (&acc)[TPW])
+{
+    if constexpr (NA >= 1) {
+        if (n_act == NA) schur_mfma_body<NA, TPW, KB, LD>(pa, pb, acc);
+        else schur_mfma_dispatch<TPW, KB, LD, NA - 1>(n_act, pa, pb, acc);
+    }
+}
+
 template <int KMAX>
-__global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
+__global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_schur_kernel(
     const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches, const uint32_t* __restrict__ chunk_slab,
     const uint32_t* __restrict__ chunk_cam, const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_pt,
     const uint8_t* __restrict__ q_slot, const double* __restrict__ ar, const double* __restrict__ campre,
@@ -526,16 +572,16 @@ __global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
     constexpr int NPIECE = kBatchObs * kRawPieces;                // 16-byte pieces per batch
     constexpr int PPT = (NPIECE + NT - 1) / NT;                   // per lane
     static_assert(NT >= 2 * kBatchObs, "W/Y staging uses two lanes per observation");
-    static_assert(KB % 4 == 0 && (2 * KB * LD) % 2 == 0, "image shape");
+    static_assert(KB % 4 == 0 && (KB * LD) % 2 == 0, "image shape");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* const raw = lds;                              // [kBatchObs][12]
-    double* const Yi = raw + kBatchObs * kRawRow;         // [KB][LD]   Yi[3 pl + c][6 slot + r] = Y~[r][c]
-    double* const Wi = Yi + KB * LD;                      // [KB][LD]
-    double* const cil = Wi + KB * LD;                     // [2][PB][6] inverse of the damped point blocks, by batch parity
-    double* const gl = cil + 2 * PB * 6;                  // [2][KB]    J_p^T r of the batch's points, index 3 pl + c
+    double* const raw = lds;                              // [kBatchObs][6]
+    double* const Ui = raw + kBatchObs * kRawRow;         // [KB][LD]   Ui[3 pl + c][6 slot + r] = U~[r][c],  U~ = W~ L^-T
+    double* const cil = Ui + KB * LD;                     // [2][PB][6] L^-T of the damped point blocks (m00 m01 m02 m11 m12 m22), by batch parity
+    double* const gl = cil + 2 * PB * 6;                  // [2][KB]    t = L^-1 J_p^T r of the batch's points, index 3 pl + c
     double* const xl = gl + 2 * KB;                       // [2][PB][3] the batch's points (linearisation point)
     double* const camtab = xl + 2 * PB * 3;               // [KMAX][10] R and branch flag of the window's cameras
-    uint8_t* const pt_l = reinterpret_cast<uint8_t*>(camtab + KMAX * kCamTab);   // batch-local point of each staged observation
+    double* const ptin = camtab + KMAX * kCamTab;         // [PB][15] the next batch's point data on its way to the point lanes
+    uint8_t* const pt_l = reinterpret_cast<uint8_t*>(ptin + PB * kPointVals);    // batch-local point of each staged observation
     uint8_t* const slot_l = pt_l + kBatchObs;                                    // its window slot (255: fixed camera)
 
     const SchurChunk ch = chunks[blockIdx.x];
@@ -550,18 +596,33 @@ __global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
         camtab[e] = campre[kPoseStride * (size_t)chunk_cam[(size_t)blockIdx.x * KMAX + slot] + (i < 9 ? i : 21)];
     }
 
-    // this wave's tiles of the upper triangle: u = wave, wave + 8, ..
+    // this wave's tiles of the upper triangle of the rows the chunk USES (a window of 11 cameras covers 5 of the 6 tile
+    // rows a 16-camera window has): the used tiles u = wave, wave + NT/64, .. are dealt round the waves, so the matrix
+    // work stays balanced whatever the window's width
     int t_i0[TPW], t_j0[TPW];
     schur_double4 acc[TPW];
+    const int nt1_used = (rows_used + 15) / 16, nup_used = nt1_used * (nt1_used + 1) / 2;
+    static_assert(TPW * (NT / 64) >= NUP && NT1 * 16 >= 6 * KMAX, "every tile of the widest window has an owner");
 #pragma unroll
     for (int j = 0; j < TPW; j++) {
         int u = wave + j * (NT / 64), ti = 0;
         t_i0[j] = -1; t_j0[j] = 0;
-        if (u < NUP) {
-            while (u >= NT1 - ti) { u -= NT1 - ti; ti++; }
-            if (ti * 16 < rows_used && (ti + u) * 16 < rows_used) { t_i0[j] = ti * 16; t_j0[j] = (ti + u) * 16; }
+        if (u < nup_used) {
+            while (u >= nt1_used - ti) { u -= nt1_used - ti; ti++; }
+            t_i0[j] = ti * 16; t_j0[j] = (ti + u) * 16;
         }
         acc[j] = schur_double4{0.0, 0.0, 0.0, 0.0};
+    }
+    // operand bases of the wave's tiles in the image (fixed for the chunk) and the number of tiles it owns
+    const double* pa[TPW];
+    const double* pb[TPW];
+    int n_act = 0;
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        const int i0 = t_i0[j] < 0 ? 0 : t_i0[j];
+        pa[j] = Ui + (lane / 16) * LD + i0 + lane % 16;
+        pb[j] = Ui + (lane / 16) * LD + t_j0[j] + lane % 16;
+        n_act += t_i0[j] >= 0 ? 1 : 0;
     }
     constexpr int kRhsGroups = 2;   // kRhsGroups * 6 KMAX <= NT lanes share the rhs product
     double racc = 0.0;   // partial rhs of row tid % rows_used
@@ -574,7 +635,12 @@ __global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
     uint32_t pre_row[PPT];     // camera-major row of each piece's observation, fetched TWO batches ahead
     uint32_t pre_pt = 0;
     uint8_t pre_slot = 255;
-    double pre_c[6], pre_s[3], pre_g[3], pre_p[3];
+    // the last wave carries the next batch's point data, three values per lane (15 per point: see kPointVals); the point
+    // lanes collect theirs through LDS inside that wave - 6 registers instead of 30 in every lane of the workgroup
+    constexpr int kPtPerLane = (PB * kPointVals + 63) / 64;
+    double pre_pv[kPtPerLane];
+#pragma unroll
+    for (int u = 0; u < kPtPerLane; u++) pre_pv[u] = 0.0;
     uint32_t p_pack[PPT];      // pass s: batch-local observation of this lane's piece | piece inside the row << 16
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
@@ -603,34 +669,59 @@ __global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
             pre_x[s] = v.x; pre_y[s] = v.y;
         }
         if (tid < nq) { pre_pt = q_pt[bt.q_begin + tid]; pre_slot = q_slot[bt.q_begin + tid]; }
-        if (ptl >= 0 && ptl < np) {
-            const size_t p = (size_t)bt.p_begin + ptl;
+        if (ptl >= 0) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) pre_c[i] = C[6 * p + i];
-#pragma unroll
-            for (int i = 0; i < 3; i++) { pre_s[i] = sp[3 * p + i]; pre_g[i] = gp[3 * p + i]; pre_p[i] = pts[3 * p + i]; }
+            for (int u = 0; u < kPtPerLane; u++) {
+                const int idx = ptl * kPtPerLane + u, pl = idx / kPointVals, v = idx - pl * kPointVals;
+                const size_t p = (size_t)bt.p_begin + pl;
+                double val = 0.0;
+                if (pl < np) val = v < 6 ? C[6 * p + v] : v < 9 ? sp[3 * p + (v - 6)] : v < 12 ? gp[3 * p + (v - 9)] : pts[3 * p + (v - 12)];
+                pre_pv[u] = val;
+            }
         }
     };
-    // One lane per point of a batch (the last wave, which owns the fewest tiles): damped 3x3 block inverted in
-    // registers, for the batch AFTER the one being multiplied - a long dependent f64 chain on a few lanes that would
-    // otherwise stall all eight waves at a barrier.  Results go to the parity buffers of that batch.
+    // One lane per point of a batch (the last wave): Cholesky factor of the damped 3x3 block, its inverse transpose
+    // M = L^-T, t = L^-1 g and C^-1 = M M^T in registers, for the batch AFTER the one being multiplied - a long dependent
+    // f64 chain on a few lanes that would otherwise stall every wave at a barrier.  Results go to the parity buffers
+    // of that batch.
     auto point_phase = [&](uint32_t bi) __attribute__((always_inline)) {
-        if (ptl < 0 || ptl >= PB) return;
+        if (ptl < 0) return;
+        // the wave's own exchange: written and read by the same wave, in program order
+#pragma unroll
+        for (int u = 0; u < kPtPerLane; u++) {
+            const int idx = ptl * kPtPerLane + u;
+            if (idx < PB * kPointVals) ptin[idx] = pre_pv[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        if (ptl >= PB) return;
+        double pre_c[6], pre_s[3], pre_g[3], pre_p[3];
+#pragma unroll
+        for (int i = 0; i < 6; i++) pre_c[i] = ptin[ptl * kPointVals + i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            pre_s[i] = ptin[ptl * kPointVals + 6 + i]; pre_g[i] = ptin[ptl * kPointVals + 9 + i]; pre_p[i] = ptin[ptl * kPointVals + 12 + i];
+        }
         const SchurBatch bt = batches[bi];
         const int np = (int)(bt.p_end - bt.p_begin);
         double* cl = cil + (bi & 1) * (PB * 6);
         double* g = gl + (bi & 1) * KB;
         double* xp = xl + (bi & 1) * (PB * 3);
         if (ptl < np) {
-            double ci[6];
+            double mt[6], ci[6];
             const double m[6] = {pre_c[0] + point_lambda(pre_c[0], pre_s[0], lm), pre_c[1], pre_c[2],
                                  pre_c[3] + point_lambda(pre_c[3], pre_s[1], lm), pre_c[4], pre_c[5] + point_lambda(pre_c[5], pre_s[2], lm)};
-            if (!sym3_inverse(m, ci)) scal[SC_SCHUR_STATUS] = 1.0;
+            if (!sym3_chol_inverse(m, mt, ci)) scal[SC_SCHUR_STATUS] = 1.0;
             double* o = Cinv + 6 * ((size_t)bt.p_begin + ptl);
 #pragma unroll
-            for (int i = 0; i < 6; i++) { cl[ptl * 6 + i] = ci[i]; o[i] = ci[i]; }
+            for (int i = 0; i < 6; i++) { cl[ptl * 6 + i] = mt[i]; o[i] = ci[i]; }
+            // t = L^-1 g = M^T g
+            g[ptl * 3] = mt[0] * pre_g[0];
+            g[ptl * 3 + 1] = mt[1] * pre_g[0] + mt[3] * pre_g[1];
+            g[ptl * 3 + 2] = mt[2] * pre_g[0] + mt[4] * pre_g[1] + mt[5] * pre_g[2];
 #pragma unroll
-            for (int i = 0; i < 3; i++) { g[ptl * 3 + i] = pre_g[i]; xp[ptl * 3 + i] = pre_p[i]; }
+            for (int i = 0; i < 3; i++) xp[ptl * 3 + i] = pre_p[i];
         } else {
             g[ptl * 3] = 0.0; g[ptl * 3 + 1] = 0.0; g[ptl * 3 + 2] = 0.0;   // k padding of the rhs product
         }
@@ -657,21 +748,21 @@ __global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
             fetch(bi + 1);
             if (bi + 2 < ch.batch_end) fetch_index(bi + 2);
         }
-        // zero both images (contiguous, 16-byte stores); absent cameras and the k padding stay zero
-        for (int e = tid; e < KB * LD; e += NT) reinterpret_cast<double2*>(Yi)[e] = make_double2(0.0, 0.0);
+        // zero the image (contiguous, 16-byte stores); absent cameras and the k padding stay zero
+        for (int e = tid; e < KB * LD / 2; e += NT) reinterpret_cast<double2*>(Ui)[e] = make_double2(0.0, 0.0);
         if (tid < nq) { pt_l[tid] = (uint8_t)(my_pt - bt.p_begin); slot_l[tid] = my_slot; }
         const double* const cil_b = cil + (bi & 1) * (PB * 6);
         const double* const gl_b = gl + (bi & 1) * KB;
         const double* const xl_b = xl + (bi & 1) * (PB * 3);
         lds_barrier();
-        // W~ and Y~ = W~ Cinv: two lanes per observation, the rotation rows (0..2) and the translation rows (3..5)
+        // U~ = W~ L^-T: two lanes per observation, the rotation rows (0..2) and the translation rows (3..5)
         if (tid < 2 * nq) {
             const int o = tid >> 1, half = tid & 1;
             const int slot = slot_l[o];
             if (slot != 255) {
                 const double* Gr = raw + o * kRawRow;
                 const int pl = pt_l[o];
-                const double* ci = cil_b + pl * 6;
+                const double* mi = cil_b + pl * 6;
                 const double* ct = camtab + slot * kCamTab;
                 double G[6], R[9], v[3], w[18];
 #pragma unroll
@@ -680,46 +771,28 @@ __global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
                 for (int i = 0; i < 9; i++) R[i] = ct[i];
                 compact_v(R, ct[9] != 0.0, xl_b + pl * 3, v);
                 compact_wt(G, R, v, w);
-                const double c0 = ci[0], c1 = ci[1], c2 = ci[2], c3 = ci[3], c4 = ci[4], c5 = ci[5];
-                double* Wc = Wi + (pl * 3) * LD + slot * 6;
-                double* Yc = Yi + (pl * 3) * LD + slot * 6;
+                const double m00 = mi[0], m01 = mi[1], m02 = mi[2], m11 = mi[3], m12 = mi[4], m22 = mi[5];
+                double* Uc = Ui + (pl * 3) * LD + slot * 6;
 #pragma unroll
                 for (int rr = 0; rr < 3; rr++) {
                     const int r = half * 3 + rr;
                     const double w0 = half ? w[(3 + rr) * 3] : w[rr * 3], w1 = half ? w[(3 + rr) * 3 + 1] : w[rr * 3 + 1],
                                  w2 = half ? w[(3 + rr) * 3 + 2] : w[rr * 3 + 2];
-                    Wc[r] = w0; Wc[LD + r] = w1; Wc[2 * LD + r] = w2;
-                    Yc[r] = w0 * c0 + w1 * c1 + w2 * c2;
-                    Yc[LD + r] = w0 * c1 + w1 * c3 + w2 * c4;
-                    Yc[2 * LD + r] = w0 * c2 + w1 * c4 + w2 * c5;
+                    Uc[r] = w0 * m00;
+                    Uc[LD + r] = w0 * m01 + w1 * m11;
+                    Uc[2 * LD + r] = w0 * m02 + w1 * m12 + w2 * m22;
                 }
             }
         }
         lds_barrier();
-        // window += Yi^T Wi over the batch's columns: lane l feeds A[i = l%16][k = l/16] and B[k = l/16][j = l%16].
-        // k outermost: the wave's tiles are independent accumulators, their products issue back to back
-        {
-            const double* pa[TPW];
-            const double* pb[TPW];
-#pragma unroll
-            for (int j = 0; j < TPW; j++) {
-                const int i0 = t_i0[j] < 0 ? 0 : t_i0[j];
-                pa[j] = Yi + (lane / 16) * LD + i0 + lane % 16;
-                pb[j] = Wi + (lane / 16) * LD + t_j0[j] + lane % 16;
-            }
-            for (int k0 = 0; k0 < kb_used; k0 += 4) {
-                double av[TPW], bv[TPW];
-#pragma unroll
-                for (int j = 0; j < TPW; j++) { av[j] = pa[j][k0 * LD]; bv[j] = pb[j][k0 * LD]; }
-#pragma unroll
-                for (int j = 0; j < TPW; j++)
-                    if (t_i0[j] >= 0) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j], acc[j], 0, 0, 0);   // wave-uniform
-            }
-        }
-        // rhs part Y~ g: lane group g = tid / rows_used takes the columns k = g (mod kRhsGroups); combined at the end
+        // window += Ui^T Ui over the batch's columns: lane l feeds A[i = l%16][k = l/16] and B[k = l/16][j = l%16], both
+        // from the one image.  Straight-line code: the wave's n_act tiles (wave-uniform) pick one fully unrolled body, all
+        // KB / 4 steps are taken (the k padding of a short batch is zero), every operand read is base + immediate offset
+        schur_mfma_dispatch<TPW, KB, LD>(n_act, pa, pb, acc);
+        // rhs part U~ t: lane group g = tid / rows_used takes the columns k = g (mod kRhsGroups); combined at the end
         if (tid < kRhsGroups * rows_used) {
             const int grp = tid / rows_used, rrow = tid - grp * rows_used;
-            const double* y = Yi + rrow;
+            const double* y = Ui + rrow;
             double s0 = 0.0, s1 = 0.0;
             int k = grp;
             for (; k + kRhsGroups < kb_used; k += 2 * kRhsGroups) {
@@ -733,7 +806,7 @@ __global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
     }
 
     // the chunk's window: [pair a <= b][6x6] then [camera][6].  Accumulator register r of lane l holds element
-    // (i0 + 4 r + l/16, j0 + l%16); the same-camera blocks are symmetric (W~ Cinv W~^T), so their lower entries are the
+    // (i0 + 4 r + l/16, j0 + l%16); the same-camera blocks are symmetric (U~ U~^T), so their lower entries are the
     // mirrored upper ones, wherever the 16x16 tiling cuts them.
     double* out = slab + chunk_slab[blockIdx.x];
     const int n_pair = K * (K + 1) / 2;
@@ -759,12 +832,12 @@ __global__ __launch_bounds__(schur_threads(KMAX)) void ba_schur_kernel(
     }
     // rhs: the lane groups' partial sums are added in a fixed order through the (now idle) image memory
     lds_barrier();
-    if (tid < kRhsGroups * rows_used) Yi[tid] = racc;
+    if (tid < kRhsGroups * rows_used) Ui[tid] = racc;
     lds_barrier();
     if (tid < rows_used) {
-        double s = Yi[tid];
+        double s = Ui[tid];
 #pragma unroll
-        for (int g = 1; g < kRhsGroups; g++) s += Yi[g * rows_used + tid];
+        for (int g = 1; g < kRhsGroups; g++) s += Ui[g * rows_used + tid];
         out[n_pair * 36 + tid] = s;
     }
 }
@@ -1173,7 +1246,14 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
                   const double* sp, LmDiag lm, double* Cinv, double* slab, double* scal)
 {
     if (!n_chunks) return;
-    if (kmax <= 16) {
+    if (kmax <= 10) {
+        // windows of at most 10 cameras (60 rows: four 16-row tiles, ten of them in the upper triangle, three per wave):
+        // the common case of the reference's tracks; 32 KB of LDS and at most 168 registers - three workgroups per CU
+        constexpr size_t lds = SchurShape<10>::lds_bytes;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ba_schur_kernel<10>), dim3(n_chunks), dim3(schur_threads(10)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
+                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
+    } else if (kmax <= 16) {
         constexpr size_t lds = SchurShape<16>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ba_schur_kernel<16>), dim3(n_chunks), dim3(schur_threads(16)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,

@@ -381,7 +381,9 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             }
         }
     }
-    h->kmax = max_track > 16 ? 32 : 16;
+    // window width of the Schur kernel: the narrowest instantiation that holds the longest windowed track (10 cameras =
+    // 60 rows fill four 16-row tiles of the matrix cores exactly; 11 would need a fifth tile row: 15 tiles instead of 10)
+    h->kmax = max_track > 16 ? 32 : (max_track > 10 ? 16 : 10);
     std::vector<uint32_t> row_first(nf + 1, 0);
     for (uint32_t f = 0; f < nf; f++) row_first[f + 1] = row_first[f] + (uint32_t)rows[f].size();
     h->n_blocks = row_first[nf];
@@ -423,7 +425,11 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SETUP_MARK("pattern");
     // Schur chunks: consecutive points whose free cameras fit kmax local slots; batches of <= 128 obs
     const int K = h->kmax;
-    const uint32_t chunk_pts_max = std::max<uint32_t>(32, std::min<uint32_t>(1024, n_pt / 512 + 1));
+    // points per chunk: about two chunks per CU (a chunk's window goes to its own slab, so finer chunks cost slab traffic in
+    // ba_schur_reduce - measured at config 3: 204-point chunks 85 us for the stage, 68-point chunks 92 us although the
+    // kernel alone is faster); narrow windows close at every change of the camera set anyway
+    uint32_t chunk_pts_max = std::max<uint32_t>(32, std::min<uint32_t>(1024, n_pt / (h->kmax <= 10 ? 448 : 512) + 1));
+    if (const char* e = std::getenv("SOSLAM_CHUNK_PTS")) chunk_pts_max = (uint32_t)std::max(1, std::atoi(e));   // development
     std::vector<SchurChunk> chunks;
     std::vector<SchurBatch> batches;
     std::vector<uint32_t> chunk_slab;                       // offset of each chunk's window in the slab

@@ -257,12 +257,13 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
                                                                      double* __restrict__ Fout, const uint32_t stagger_10ns)
 {
     extern __shared__ double lds[];
-    // Test hook (SOSLAM_CR_STAGGER, tests/test_ba_gpu.py::test_cyclic_reduction_tiles_do_not_race): the first column tile of
+    // Development hook (SOSLAM_CR_STAGGER): the first column tile of
     // every node starts late by the given time, as it may on a busy or shared device, so that any dependence of one
     // workgroup of this launch on the loads of another shows every time instead of once in a while.  Bounded wait.
     if (stagger_10ns && blockIdx.y == 0) {
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
         while (__builtin_amdgcn_s_memrealtime() - t0 < stagger_10ns) __builtin_amdgcn_s_sleep(16);
+        asm volatile("" ::: "memory");   // the operand loads below must not be hoisted above the wait
     }
     const int sb = v.sb, tid = threadIdx.x;
     const size_t sb2 = (size_t)sb * sb;
