@@ -73,6 +73,15 @@ void soslam_pg_destroy(soslam_pg* h);
  * keeps the accumulated vertices/edges and uploads them again - a few hundred kB). */
 int soslam_pg_set_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_t* fixed, uint32_t n_edge,
                         const uint32_t* e_from, const uint32_t* e_to, const double* meas, const double* info36);
+/*
+ * The reference's optimizer persists and GROWS between calls (m_last_id, /root/reference/src/pose_graph_optimizer.cpp:56-59):
+ * append new vertices (with their initial estimates and fixed flags) and new edges to the handle's graph.  Existing
+ * vertices keep the estimates the last soslam_pg_optimize left on the device, as g2o's vertices do.  The first call
+ * (empty handle) needs info36; later calls may pass NULL to keep it.  Edge endpoints index the grown vertex list.
+ */
+int soslam_pg_append(soslam_pg* h, uint32_t n_add_vertex, const double* est_add, const uint8_t* fixed_add, uint32_t n_add_edge,
+                     const uint32_t* e_from, const uint32_t* e_to, const double* meas, const double* info36);
+int soslam_pg_graph_size(soslam_pg* h, uint32_t* n_vertex, uint32_t* n_edge);
 /* g2o's optimize(max_iterations): Levenberg iterations on the uploaded graph */
 int soslam_pg_optimize(soslam_pg* h, soslam_pg_summary* summary);
 int soslam_pg_get_estimates(soslam_pg* h, double* est);

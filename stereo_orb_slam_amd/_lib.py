@@ -98,7 +98,8 @@ SYNTH_SYMBOLS = [
 ]
 
 PG_SYMBOLS = [
-    "soslam_pg_options_default", "soslam_pg_create", "soslam_pg_destroy", "soslam_pg_set_graph", "soslam_pg_optimize",
+    "soslam_pg_options_default", "soslam_pg_create", "soslam_pg_destroy", "soslam_pg_set_graph", "soslam_pg_append",
+    "soslam_pg_graph_size", "soslam_pg_optimize",
     "soslam_pg_get_estimates", "soslam_pg_get_iteration_log", "soslam_pg_solve", "soslam_pg_debug_linearize",
     "soslam_pg_time_linearize",
 ]

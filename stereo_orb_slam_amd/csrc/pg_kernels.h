@@ -15,9 +15,15 @@ struct PgEdgeBlocks {
     int32_t fi, fj, diag_i, diag_j, off, off_is_ji;
 };
 
+// per-edge record of the linearisation: [J_i^T W J_i (36) | J_j^T W J_j (36) | off-diagonal block as stored (36) | -J_i^T W e (6) |
+// -J_j^T W e (6)]; parts that belong to a fixed vertex are not written (and never read)
+constexpr int kPgEdgeRec = 120;
 void launch_pg_linearize(hipStream_t s, uint32_t n_edge, const double* est, const uint32_t* ef, const uint32_t* et,
-                         const double* meas, const PgInfo& info, double delta, const PgEdgeBlocks* eb, double* H, double* b,
+                         const double* meas, const PgInfo& info, double delta, const PgEdgeBlocks* eb, double* econ,
                          double* chi_part, double* dbg_e, double* dbg_ji, double* dbg_jj);
+// H (every block) and b (every free vertex) = sums of the edge records through host-built lists, fixed order
+void launch_pg_gather(hipStream_t s, uint32_t n_blocks, const uint32_t* ptr, const uint32_t* ent, const uint32_t* blk_row,
+                      const uint32_t* blk_col, const double* econ, double* H, double* b);
 void launch_pg_chi2(hipStream_t s, uint32_t n_edge, const double* est, const uint32_t* ef, const uint32_t* et,
                     const double* meas, const PgInfo& info, double delta, double* chi_part);
 // out[0] = sum(part[0..n)); if diag_block: out[1] = max |diag(H)|

@@ -132,8 +132,8 @@ __device__ __forceinline__ void atwb(const double* __restrict__ A, const double*
 __global__ __launch_bounds__(128) void pg_linearize_kernel(uint32_t n_edge, const double* __restrict__ est,
                                                            const uint32_t* __restrict__ ef, const uint32_t* __restrict__ et,
                                                            const double* __restrict__ meas, const PgInfo info, const double delta,
-                                                           const PgEdgeBlocks* __restrict__ eb, double* __restrict__ H,
-                                                           double* __restrict__ b, double* __restrict__ chi_part,
+                                                           const PgEdgeBlocks* __restrict__ eb, double* __restrict__ econ,
+                                                           double* __restrict__ chi_part,
                                                            double* __restrict__ dbg_e, double* __restrict__ dbg_ji,
                                                            double* __restrict__ dbg_jj)
 {
@@ -171,16 +171,19 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(uint32_t n_edge, cons
                 for (int m = 0; m < 6; m++) s += info.m[a * 6 + m] * ji[m * 6 + c];
                 WJ[a * 6 + c] = rho1 * s;
             }
+        // every edge writes its own record [H_ii | H_jj | H_off as stored | b_i | b_j]; pg_gather sums the records of a
+        // block in the fixed order of host-built lists - no floating-point atomics, bitwise reproducible
+        double* rec = econ + kPgEdgeRec * (size_t)k;
         if (bl.fi >= 0) {
             atwb(ji, WJ, blk);
 #pragma unroll
-            for (int i = 0; i < 36; i++) unsafeAtomicAdd(H + 36 * (size_t)bl.diag_i + i, blk[i]);
+            for (int i = 0; i < 36; i++) rec[i] = blk[i];
 #pragma unroll
             for (int a = 0; a < 6; a++) {
                 double s = 0.0;
 #pragma unroll
                 for (int m = 0; m < 6; m++) s += ji[m * 6 + a] * We[m];
-                unsafeAtomicAdd(b + 6 * (size_t)bl.fi + a, -s);
+                rec[108 + a] = -s;
             }
         }
         if (bl.off >= 0) {
@@ -188,12 +191,12 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(uint32_t n_edge, cons
             atwb(jj, WJ, blk);   // Jj^T W Ji : rows of j, columns of i
             if (bl.off_is_ji) {
 #pragma unroll
-                for (int i = 0; i < 36; i++) unsafeAtomicAdd(H + 36 * (size_t)bl.off + i, blk[i]);
+                for (int i = 0; i < 36; i++) rec[72 + i] = blk[i];
             } else {
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
-                    for (int c = 0; c < 6; c++) unsafeAtomicAdd(H + 36 * (size_t)bl.off + c * 6 + a, blk[a * 6 + c]);
+                    for (int c = 0; c < 6; c++) rec[72 + c * 6 + a] = blk[a * 6 + c];
             }
         }
         if (bl.fj >= 0) {
@@ -208,13 +211,13 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(uint32_t n_edge, cons
                 }
             atwb(jj, WJ, blk);
 #pragma unroll
-            for (int i = 0; i < 36; i++) unsafeAtomicAdd(H + 36 * (size_t)bl.diag_j + i, blk[i]);
+            for (int i = 0; i < 36; i++) rec[36 + i] = blk[i];
 #pragma unroll
             for (int a = 0; a < 6; a++) {
                 double s = 0.0;
 #pragma unroll
                 for (int m = 0; m < 6; m++) s += jj[m * 6 + a] * We[m];
-                unsafeAtomicAdd(b + 6 * (size_t)bl.fj + a, -s);
+                rec[114 + a] = -s;
             }
         }
     }
@@ -222,6 +225,28 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(uint32_t n_edge, cons
     if (threadIdx.x % 64 == 0) red[threadIdx.x / 64] = rho0;
     __syncthreads();
     if (threadIdx.x == 0) chi_part[blockIdx.x] = red[0] + red[1];
+}
+
+// H and b from the per-edge records: workgroup = one block of the upper block-sparse H.  ptr/ent: per block the records
+// that feed it, ent = 2 * edge + side (diagonal blocks: side 0 = the edge's i vertex, 1 = its j vertex; the same list
+// gives b of that vertex) or the edge index (off-diagonal blocks).  Fixed order, every element of H and b written.
+__global__ __launch_bounds__(64) void pg_gather_kernel(uint32_t n_blocks, const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ ent,
+                                                       const uint32_t* __restrict__ blk_row, const uint32_t* __restrict__ blk_col,
+                                                       const double* __restrict__ econ, double* __restrict__ H, double* __restrict__ b)
+{
+    const uint32_t id = blockIdx.x;
+    const int t = threadIdx.x;
+    if (id >= n_blocks || t >= 42) return;
+    const bool diag = blk_row[id] == blk_col[id];
+    if (!diag && t >= 36) return;
+    double s = 0.0;
+    for (uint32_t e = ptr[id]; e < ptr[id + 1]; e++) {
+        const uint32_t v = ent[e];
+        const double* rec = econ + kPgEdgeRec * (size_t)(diag ? v >> 1 : v);
+        s += diag ? (t < 36 ? rec[36 * (v & 1) + t] : rec[108 + 6 * (v & 1) + (t - 36)]) : rec[72 + t];
+    }
+    if (t < 36) H[36 * (size_t)id + t] = s;
+    else b[6 * (size_t)blk_row[id] + (t - 36)] = s;
 }
 
 __global__ __launch_bounds__(256) void pg_chi2_kernel(uint32_t n_edge, const double* __restrict__ est,
@@ -309,12 +334,19 @@ __global__ __launch_bounds__(256) void pg_update_kernel(uint32_t n_vertex, const
 }  // namespace
 
 void launch_pg_linearize(hipStream_t s, uint32_t n_edge, const double* est, const uint32_t* ef, const uint32_t* et,
-                         const double* meas, const PgInfo& info, double delta, const PgEdgeBlocks* eb, double* H, double* b,
+                         const double* meas, const PgInfo& info, double delta, const PgEdgeBlocks* eb, double* econ,
                          double* chi_part, double* dbg_e, double* dbg_ji, double* dbg_jj)
 {
     if (!n_edge) return;
     hipLaunchKernelGGL(pg_linearize_kernel, dim3((n_edge + 127) / 128), dim3(128), 0, s, n_edge, est, ef, et, meas, info, delta, eb,
-                       H, b, chi_part, dbg_e, dbg_ji, dbg_jj);
+                       econ, chi_part, dbg_e, dbg_ji, dbg_jj);
+}
+
+void launch_pg_gather(hipStream_t s, uint32_t n_blocks, const uint32_t* ptr, const uint32_t* ent, const uint32_t* blk_row,
+                      const uint32_t* blk_col, const double* econ, double* H, double* b)
+{
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(pg_gather_kernel, dim3(n_blocks), dim3(64), 0, s, n_blocks, ptr, ent, blk_row, blk_col, econ, H, b);
 }
 
 void launch_pg_chi2(hipStream_t s, uint32_t n_edge, const double* est, const uint32_t* ef, const uint32_t* et,

@@ -24,8 +24,13 @@ struct soslam_pg {
     PgInfo info{};
     std::vector<int32_t> h_free;
     std::vector<uint32_t> h_blk_row, h_blk_col;
-    DevBuf<double> est[2], meas, H, b, x, resid, work, chi_part, chi_part_lin, scale_part, scal;
-    DevBuf<uint32_t> ef, et, row_ptr, ent_col, ent_blk;
+    // host mirror of the graph: soslam_pg_append extends it (the reference's g2o optimizer persists and grows between
+    // calls, /root/reference/src/pose_graph_optimizer.cpp:56-59); estimates of existing vertices live on the device
+    std::vector<double> g_est, g_meas;
+    std::vector<uint8_t> g_fixed;
+    std::vector<uint32_t> g_ef, g_et;
+    DevBuf<double> est[2], meas, H, b, x, resid, work, chi_part, chi_part_lin, scale_part, scal, econ;
+    DevBuf<uint32_t> ef, et, row_ptr, ent_col, ent_blk, g_ptr, g_ent, blk_row, blk_col;
     DevBuf<uint8_t> ent_trans;
     DevBuf<int32_t> free_idx, diag_block;
     DevBuf<PgEdgeBlocks> eb;
@@ -108,6 +113,21 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
         }
         eb[k] = e;
     }
+    // gather lists of pg_gather: per block of H the edge records that feed it, in edge order
+    std::vector<uint32_t> g_ptr(h->n_blocks + 1, 0), g_ent;
+    {
+        std::vector<std::vector<uint32_t>> lists(h->n_blocks);
+        for (uint32_t k = 0; k < n_edge; k++) {
+            const PgEdgeBlocks& e = eb[k];
+            if (e.fi >= 0) lists[(size_t)e.diag_i].push_back(2 * k);
+            if (e.fj >= 0) lists[(size_t)e.diag_j].push_back(2 * k + 1);
+            if (e.off >= 0) lists[(size_t)e.off].push_back(k);
+        }
+        for (uint32_t blk = 0; blk < h->n_blocks; blk++) {
+            g_ptr[blk + 1] = g_ptr[blk] + (uint32_t)lists[blk].size();
+            g_ent.insert(g_ent.end(), lists[blk].begin(), lists[blk].end());
+        }
+    }
     std::vector<uint32_t> row_ptr(nf + 1, 0), ent_col, ent_blk;
     std::vector<uint8_t> ent_trans;
     {
@@ -143,6 +163,11 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     SOSLAM_CHECK(h->ent_col.upload(ent_col, s));
     SOSLAM_CHECK(h->ent_blk.upload(ent_blk, s));
     SOSLAM_CHECK(h->ent_trans.upload(ent_trans, s));
+    SOSLAM_CHECK(h->g_ptr.upload(g_ptr, s));
+    SOSLAM_CHECK(h->g_ent.upload(g_ent, s));
+    SOSLAM_CHECK(h->blk_row.upload(h->h_blk_row, s));
+    SOSLAM_CHECK(h->blk_col.upload(h->h_blk_col, s));
+    SOSLAM_CHECK(h->econ.alloc((size_t)n_edge * kPgEdgeRec));
     SOSLAM_CHECK(h->H.alloc((size_t)h->n_blocks * 36));
     SOSLAM_CHECK(h->b.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->x.alloc((size_t)nf * 6));
@@ -157,6 +182,13 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     h->cur = 0;
     h->have_graph = true;
     h->setup_seconds = now_sec() - t0;
+    // keep the graph for soslam_pg_append (the estimates are refreshed from the device when it is called)
+    h->g_est.assign(est, est + 7 * (size_t)n_vertex);
+    h->g_meas.assign(meas, meas + 7 * (size_t)n_edge);
+    h->g_fixed.assign(n_vertex, 0);
+    if (fixed) h->g_fixed.assign(fixed, fixed + n_vertex);
+    h->g_ef.assign(ef, ef + n_edge);
+    h->g_et.assign(et, et + n_edge);
     return SOSLAM_OK;
 }
 
@@ -164,10 +196,9 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
 int linearize(soslam_pg* h, double* dbg_e, double* dbg_ji, double* dbg_jj)
 {
     hipStream_t s = h->stream;
-    SOSLAM_CHECK(h->H.zero(s));
-    SOSLAM_CHECK(h->b.zero(s));
-    launch_pg_linearize(s, h->n_edge, h->est[h->cur].p, h->ef.p, h->et.p, h->meas.p, h->info, h->opt.huber_delta, h->eb.p, h->H.p,
-                        h->b.p, h->chi_part_lin.p, dbg_e, dbg_ji, dbg_jj);
+    launch_pg_linearize(s, h->n_edge, h->est[h->cur].p, h->ef.p, h->et.p, h->meas.p, h->info, h->opt.huber_delta, h->eb.p, h->econ.p,
+                        h->chi_part_lin.p, dbg_e, dbg_ji, dbg_jj);
+    launch_pg_gather(s, h->n_blocks, h->g_ptr.p, h->g_ent.p, h->blk_row.p, h->blk_col.p, h->econ.p, h->H.p, h->b.p);
     launch_pg_reduce(s, h->chi_part_lin.p, h->n_chi_part, h->H.p, h->diag_block.p, h->n_free, h->scal.p);
     SOSLAM_HIP_CHECK(hipGetLastError());
     return SOSLAM_OK;
@@ -332,6 +363,46 @@ int soslam_pg_set_graph(soslam_pg* h, uint32_t n_vertex, const double* est, cons
     return build_graph(h, n_vertex, est, fixed, n_edge, e_from, e_to, meas, info36);
 }
 
+int soslam_pg_append(soslam_pg* h, uint32_t n_add_vertex, const double* est_add, const uint8_t* fixed_add, uint32_t n_add_edge,
+                     const uint32_t* e_from, const uint32_t* e_to, const double* meas, const double* info36)
+{
+    if (!h || (n_add_vertex && !est_add) || (n_add_edge && (!e_from || !e_to || !meas))) return SOSLAM_ERR_INVALID_ARGUMENT;
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    if (!h->have_graph) {
+        if (!info36 || !n_add_vertex) { set_last_error("the first append needs vertices and the information matrix"); return SOSLAM_ERR_INVALID_ARGUMENT; }
+        return build_graph(h, n_add_vertex, est_add, fixed_add, n_add_edge, e_from, e_to, meas, info36);
+    }
+    // the existing vertices keep the estimates the last optimisation left on the device (as g2o's vertices do)
+    std::vector<double> est(h->g_est.size());
+    SOSLAM_HIP_CHECK(hipMemcpyAsync(est.data(), h->est[h->cur].p, sizeof(double) * est.size(), hipMemcpyDeviceToHost, h->stream));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<double> meas_all(h->g_meas);
+    std::vector<uint8_t> fixed(h->g_fixed);
+    std::vector<uint32_t> ef(h->g_ef), et(h->g_et);
+    est.insert(est.end(), est_add, est_add + 7 * (size_t)n_add_vertex);
+    for (uint32_t v = 0; v < n_add_vertex; v++) fixed.push_back(fixed_add ? fixed_add[v] : 0);
+    if (n_add_edge) {
+        meas_all.insert(meas_all.end(), meas, meas + 7 * (size_t)n_add_edge);
+        ef.insert(ef.end(), e_from, e_from + n_add_edge);
+        et.insert(et.end(), e_to, e_to + n_add_edge);
+    }
+    double info[36];
+    std::memcpy(info, info36 ? info36 : h->info.m, sizeof info);
+    // the block pattern and the gather lists depend on the whole edge set: rebuilt; buffers are kept (grow-only)
+    const int st = build_graph(h, (uint32_t)fixed.size(), est.data(), fixed.data(), (uint32_t)ef.size(), ef.data(), et.data(),
+                               meas_all.data(), info);
+    if (st != SOSLAM_OK) h->have_graph = false;   // a rejected append leaves no half-built graph behind
+    return st;
+}
+
+int soslam_pg_graph_size(soslam_pg* h, uint32_t* n_vertex, uint32_t* n_edge)
+{
+    if (!h) return SOSLAM_ERR_INVALID_ARGUMENT;
+    if (n_vertex) *n_vertex = h->have_graph ? h->n_vertex : 0;
+    if (n_edge) *n_edge = h->have_graph ? h->n_edge : 0;
+    return SOSLAM_OK;
+}
+
 int soslam_pg_optimize(soslam_pg* h, soslam_pg_summary* summary)
 {
     if (!h) return SOSLAM_ERR_INVALID_ARGUMENT;
@@ -416,8 +487,9 @@ int soslam_pg_time_linearize(soslam_pg* h, int32_t reps, float* avg_ms)
     SOSLAM_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     auto once = [&]() {
-        launch_pg_linearize(s, h->n_edge, h->est[h->cur].p, h->ef.p, h->et.p, h->meas.p, h->info, h->opt.huber_delta, h->eb.p, h->H.p,
-                            h->b.p, h->chi_part_lin.p, nullptr, nullptr, nullptr);
+        launch_pg_linearize(s, h->n_edge, h->est[h->cur].p, h->ef.p, h->et.p, h->meas.p, h->info, h->opt.huber_delta, h->eb.p, h->econ.p,
+                            h->chi_part_lin.p, nullptr, nullptr, nullptr);
+        launch_pg_gather(s, h->n_blocks, h->g_ptr.p, h->g_ent.p, h->blk_row.p, h->blk_col.p, h->econ.p, h->H.p, h->b.p);
     };
     once();
     SOSLAM_HIP_CHECK(hipEventRecord(h->ev[0], s));

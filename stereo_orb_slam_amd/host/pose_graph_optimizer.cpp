@@ -36,6 +36,8 @@ PoseGraphOptimizer::PoseGraphOptimizer(BundleAdjuster& ba, std::vector<Frame*>& 
     for (int i = 0; i < 6; i++) m_information[i * 7] = i < 3 ? 0.01 : 1.0;
 }
 
+PoseGraphOptimizer::~PoseGraphOptimizer() { soslam_pg_destroy(m_pg); }
+
 void PoseGraphOptimizer::AddLoopMeasurement(int id_1, int id_2, const Mat4f& trans) { m_loop_meas[{id_1, id_2}] = trans; }
 
 void PoseGraphOptimizer::AddOdometryConstraints(unsigned int start_frame_id, unsigned int end_frame_id)
@@ -90,11 +92,22 @@ void PoseGraphOptimizer::Optimize()
     for (unsigned char f : m_fixed) any_fixed = any_fixed || f;
     if (!any_fixed && !m_fixed.empty()) m_fixed[0] = 1;
 
-    std::vector<double> est(m_vertices.size() * 7), meas(m_edge_meas.size() * 7);
-    for (size_t i = 0; i < m_vertices.size(); i++) for (int a = 0; a < 7; a++) est[7 * i + a] = m_vertices[i][a];
-    for (size_t i = 0; i < m_edge_meas.size(); i++) for (int a = 0; a < 7; a++) meas[7 * i + a] = m_edge_meas[i][a];
-    m_status = soslam_pg_solve(&m_options, (uint32_t)m_vertices.size(), est.data(), m_fixed.data(), (uint32_t)m_edge_from.size(),
-                               m_edge_from.data(), m_edge_to.data(), meas.data(), m_information.data(), &m_summary);
+    // the device-resident graph: created once, then only what is new since the last call is appended
+    if (!m_pg) m_status = soslam_pg_create(&m_options, &m_pg);
+    if (m_status == SOSLAM_OK) {
+        const size_t nv = m_vertices.size() - m_sent_vertices, ne = m_edge_from.size() - m_sent_edges;
+        std::vector<double> est_add(nv * 7), meas_add(ne * 7);
+        for (size_t i = 0; i < nv; i++) for (int a = 0; a < 7; a++) est_add[7 * i + a] = m_vertices[m_sent_vertices + i][a];
+        for (size_t i = 0; i < ne; i++) for (int a = 0; a < 7; a++) meas_add[7 * i + a] = m_edge_meas[m_sent_edges + i][a];
+        if (nv || ne)
+            m_status = soslam_pg_append(m_pg, (uint32_t)nv, nv ? est_add.data() : nullptr, nv ? m_fixed.data() + m_sent_vertices : nullptr,
+                                        (uint32_t)ne, ne ? m_edge_from.data() + m_sent_edges : nullptr,
+                                        ne ? m_edge_to.data() + m_sent_edges : nullptr, ne ? meas_add.data() : nullptr, m_information.data());
+        if (m_status == SOSLAM_OK) { m_sent_vertices = m_vertices.size(); m_sent_edges = m_edge_from.size(); }
+    }
+    std::vector<double> est(m_vertices.size() * 7);
+    if (m_status == SOSLAM_OK) m_status = soslam_pg_optimize(m_pg, &m_summary);
+    if (m_status == SOSLAM_OK) m_status = soslam_pg_get_estimates(m_pg, est.data());
     if (m_status != SOSLAM_OK) {
         std::fprintf(stderr, "[FAIL]: pose graph optimisation failed: %s (%s)\n", soslam_status_string(m_status), soslam_last_error());
         return;

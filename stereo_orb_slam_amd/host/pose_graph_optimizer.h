@@ -1,7 +1,10 @@
 // pose_graph_optimizer.h - host shim with the reference's entry point
 //   PoseGraphOptimizer(BundleAdjuster&, std::vector<Frame*>&, std::vector<PoseGraphEdge>&); void Optimize();
 // (/root/reference/src/pose_graph_optimizer.h:18-50).  The g2o graph the reference keeps inside the object
-// (vertices, edges, m_last_id) is kept here as plain arrays and handed to soslam_pg_solve on every call.
+// (vertices, edges, m_last_id; it persists and grows between calls, pose_graph_optimizer.cpp:56-59) lives in ONE device
+// handle for the object's lifetime: every Optimize() appends the new vertices and edges (soslam_pg_append), the
+// estimates of the existing vertices stay on the device between calls as g2o's do.  The arrays below mirror it for
+// SavePoseGraph and the write-back.
 #pragma once
 
 #include <array>
@@ -17,6 +20,9 @@
 class PoseGraphOptimizer {
 public:
     PoseGraphOptimizer(BundleAdjuster& ba, std::vector<Frame*>& cam_frames, std::vector<PoseGraphEdge>& edges);
+    ~PoseGraphOptimizer();
+    PoseGraphOptimizer(const PoseGraphOptimizer&) = delete;
+    PoseGraphOptimizer& operator=(const PoseGraphOptimizer&) = delete;
 
     void Optimize();
 
@@ -54,4 +60,7 @@ private:
     soslam_pg_options m_options;
     soslam_pg_summary m_summary{};
     int m_status = 0;
+    soslam_pg* m_pg = nullptr;        // the device-resident graph, created at the first Optimize()
+    size_t m_sent_vertices = 0;       // how much of m_vertices / m_edge_* the handle already holds
+    size_t m_sent_edges = 0;
 };

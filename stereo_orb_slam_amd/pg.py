@@ -29,7 +29,8 @@ class PgSummary(C.Structure):
     ]
 
 
-PG_SYMBOLS = ["soslam_pg_options_default", "soslam_pg_create", "soslam_pg_destroy", "soslam_pg_set_graph", "soslam_pg_optimize",
+PG_SYMBOLS = ["soslam_pg_options_default", "soslam_pg_create", "soslam_pg_destroy", "soslam_pg_set_graph", "soslam_pg_append",
+              "soslam_pg_graph_size", "soslam_pg_optimize",
               "soslam_pg_get_estimates", "soslam_pg_get_iteration_log", "soslam_pg_solve", "soslam_pg_debug_linearize",
               "soslam_pg_time_linearize"]
 _bound = False
@@ -46,6 +47,8 @@ def _L():
         L.soslam_pg_destroy.argtypes = [vp]
         L.soslam_pg_destroy.restype = None
         L.soslam_pg_set_graph.argtypes = [vp, u32, vp, vp, u32, vp, vp, vp, vp]
+        L.soslam_pg_append.argtypes = [vp, u32, vp, vp, u32, vp, vp, vp, vp]
+        L.soslam_pg_graph_size.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
         L.soslam_pg_optimize.argtypes = [vp, C.POINTER(PgSummary)]
         L.soslam_pg_get_estimates.argtypes = [vp, vp]
         L.soslam_pg_get_iteration_log.argtypes = [vp, vp, i32, C.POINTER(i32)]
@@ -98,6 +101,22 @@ class PoseGraph:
         _lib.check(self._L.soslam_pg_set_graph(self._h, len(est), _lib.ptr(est), _lib.ptr(fx), len(ef), _lib.ptr(ef), _lib.ptr(et),
                                                _lib.ptr(ms), _lib.ptr(inf)), "soslam_pg_set_graph")
         self.n_vertex, self.n_edge, self.n_free = len(est), len(ef), len(est) - int(fx.astype(bool).sum())
+
+    def append(self, est_add, fixed_add, e_from, e_to, meas, info=None):
+        """Grow the handle's graph (soslam_pg_append): new vertices and edges; existing vertices keep the estimates the last
+        optimize() left on the device."""
+        est = np.ascontiguousarray(est_add, np.float64).reshape(-1, 7)
+        fx = np.ascontiguousarray(fixed_add, np.uint8)
+        ef, et = np.ascontiguousarray(e_from, np.uint32), np.ascontiguousarray(e_to, np.uint32)
+        ms = np.ascontiguousarray(meas, np.float64).reshape(-1, 7)
+        inf = None if info is None else np.ascontiguousarray(info, np.float64).reshape(36)
+        _lib.check(self._L.soslam_pg_append(self._h, len(est), _lib.ptr(est) if len(est) else None, _lib.ptr(fx) if len(fx) else None,
+                                            len(ef), _lib.ptr(ef) if len(ef) else None, _lib.ptr(et) if len(et) else None,
+                                            _lib.ptr(ms) if len(ms) else None, _lib.ptr(inf)), "soslam_pg_append")
+        nv, ne = C.c_uint32(), C.c_uint32()
+        _lib.check(self._L.soslam_pg_graph_size(self._h, C.byref(nv), C.byref(ne)), "soslam_pg_graph_size")
+        self.n_free = (self.n_free if self.n_vertex else 0) + len(est) - int(fx.astype(bool).sum())
+        self.n_vertex, self.n_edge = nv.value, ne.value
 
     def load(self, g):
         self.set_graph(g.est, g.fixed, g.e_from, g.e_to, g.meas, g.info)

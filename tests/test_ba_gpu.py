@@ -633,19 +633,22 @@ def test_dense_solver_sizes_around_the_one_workgroup_limit(gpu, oracle_lib, n_ca
     assert sc[1] == pytest.approx(ref["model_cost_change"], rel=1e-7) and sc[5] == 0
 
 
-def test_config3_first_iterations_match_the_oracle(gpu, oracle_lib):
-    """BASELINE.json configs[2] at full size (500 / 100k / 1M observations): ten LM iterations on the GPU (PCG on the
+@pytest.mark.parametrize("iters,pcg_tol", [(10, 1e-10), (20, 1e-8)])
+def test_config3_first_iterations_match_the_oracle(gpu, oracle_lib, iters, pcg_tol):
+    """BASELINE.json configs[2] at full size (500 / 100k / 1M observations): LM iterations on the GPU (PCG on the
     Schur system, the bench configuration) against the CPU oracle on the same inputs - cost to 1e-5 relative, poses to
-    1e-4, every iterate, not only the last."""
+    1e-4, every iterate, not only the last.  Once at the library's default tolerance, and once exactly as bench.py's
+    timed run goes: 20 iterations with the PCG stopped at 1e-8 (the reference's solver is direct and has no such knob;
+    SURVEY.md section 6 asks for the speed tolerance to be stated - this is the parity test that covers it)."""
     ba, synth, L = gpu
     p = synth.generate_ba(3)
-    with ba.BundleAdjustment(ba.default_options(linear_solver=2, pcg_tolerance=1e-10, max_iterations=10, check_termination=0)) as h:
+    with ba.BundleAdjustment(ba.default_options(linear_solver=2, pcg_tolerance=pcg_tol, max_iterations=iters, check_termination=0)) as h:
         h.load(p)
         summ = h.solve()
         cams, pts = h.get_state()
         glog = h.iteration_log()
-    ocams, opts_, osum, olog = _oracle_solve(oracle_lib, p, max_iterations=10, check_termination=0, num_threads=16)
-    assert len(glog) == len(olog)
+    ocams, opts_, osum, olog = _oracle_solve(oracle_lib, p, max_iterations=iters, check_termination=0, num_threads=16)
+    assert len(glog) == len(olog) == iters + 1
     for a, b in zip(glog, olog):
         assert a.cost == pytest.approx(b.cost, rel=REL_COST) and a.accepted == b.accepted
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
