@@ -125,7 +125,8 @@ typedef struct soslam_ba_summary {
     int32_t iterations;
     int32_t accepted;
     int32_t termination;
-    int32_t armijo_violations;   /* see DESIGN.md: where Ceres' bounded line search would have differed */
+    int32_t line_search_steps;   /* Solver::Summary::num_line_search_steps: iterations of the Armijo search Ceres runs on bounded
+                                    problems before a step is judged (/root/reference/src/bundle_adjuster.cpp:104-108) */
     int32_t linear_solver;       /* solver actually used */
     int32_t linear_iterations;   /* total PCG iterations */
     double  solve_seconds;       /* host wall time of the LM loop (device work included) */

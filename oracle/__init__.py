@@ -44,7 +44,7 @@ class BaIteration(C.Structure):
 class BaSummary(C.Structure):
     _fields_ = [
         ("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int32),
-        ("accepted", C.c_int32), ("termination", C.c_int32), ("armijo_violations", C.c_int32),
+        ("accepted", C.c_int32), ("termination", C.c_int32), ("line_search_steps", C.c_int32),
         ("solve_seconds", C.c_double), ("setup_seconds", C.c_double),
     ]
 

@@ -735,6 +735,207 @@ int oracle_ba_step_sharded(uint32_t n_rank, uint32_t n_cam, uint32_t n_pt, uint3
     return rc;
 }
 
+/* ---- Ceres' line search on bounded problems ---------------------------------------------------------------------
+ * /root/reference/src/bundle_adjuster.cpp:104-108 bounds every point coordinate, which makes the problem "constrained":
+ * TrustRegionMinimizer::Minimize then calls DoLineSearch(x, gradient, cost, &delta) on every valid step BEFORE the
+ * candidate is evaluated - an ARMIJO search (ceres line_search.cc, ArmijoLineSearch::DoSearch) along the projected step
+ * with the defaults the reference leaves alone: sufficient decrease 1e-4, CUBIC interpolation (so the gradient is
+ * evaluated at every trial), contraction limits [1e-3, 0.6] per step, min step size 1e-9, at most 20 iterations.  On
+ * success delta is scaled by the step size found; the model cost change stays that of the full step.
+ * Restated from public sources - PARITY UNPINNED like the rest of this file.  Not restated to the
+ * bit: Ceres solves the interpolation conditions with Eigen's FullPivLU and finds the roots of a quartic derivative
+ * through the eigenvalues of a balanced companion matrix; here partial-pivoted elimination and Aberth iteration give the
+ * same numbers to rounding. */
+typedef struct { double x, value, gradient; int value_ok, gradient_ok; } ls_sample;
+
+static double poly_eval(const double* c, int deg, double x)   /* c[0] x^deg + ... + c[deg] */
+{
+    double v = 0.0;
+    for (int i = 0; i <= deg; i++) v = v * x + c[i];
+    return v;
+}
+
+/* coefficients (highest power first) of the polynomial through the samples' values and gradients; returns the degree */
+static int find_interpolating_polynomial(const ls_sample* s, int n, double* coef)
+{
+    int nc = 0;
+    for (int i = 0; i < n; i++) nc += s[i].value_ok + s[i].gradient_ok;
+    const int deg = nc - 1;
+    double a[6][7];
+    int row = 0;
+    for (int i = 0; i < n; i++) {
+        if (s[i].value_ok) {
+            for (int j = 0; j <= deg; j++) a[row][j] = pow(s[i].x, deg - j);
+            a[row][nc] = s[i].value; row++;
+        }
+        if (s[i].gradient_ok) {
+            for (int j = 0; j < deg; j++) a[row][j] = (deg - j) * pow(s[i].x, deg - j - 1);
+            a[row][deg] = 0.0;
+            a[row][nc] = s[i].gradient; row++;
+        }
+    }
+    for (int k = 0; k < nc; k++) {   /* Gaussian elimination, partial pivoting */
+        int piv = k;
+        for (int r = k + 1; r < nc; r++) if (fabs(a[r][k]) > fabs(a[piv][k])) piv = r;
+        if (piv != k) for (int j = 0; j <= nc; j++) { const double t = a[k][j]; a[k][j] = a[piv][j]; a[piv][j] = t; }
+        if (a[k][k] == 0.0) continue;
+        for (int r = k + 1; r < nc; r++) {
+            const double f = a[r][k] / a[k][k];
+            for (int j = k; j <= nc; j++) a[r][j] -= f * a[k][j];
+        }
+    }
+    for (int k = nc - 1; k >= 0; k--) {
+        double v = a[k][nc];
+        for (int j = k + 1; j < nc; j++) v -= a[k][j] * coef[j];
+        coef[k] = a[k][k] != 0.0 ? v / a[k][k] : 0.0;
+    }
+    return deg;
+}
+
+/* real parts of the roots of c[0] x^deg + ... + c[deg] (deg <= 4); returns how many */
+static int polynomial_root_real_parts(const double* c_in, int deg, double* re)
+{
+    while (deg > 0 && c_in[0] == 0.0) { c_in++; deg--; }   /* RemoveLeadingZeros */
+    if (deg <= 0) return 0;
+    if (deg == 1) { re[0] = -c_in[1] / c_in[0]; return 1; }
+    if (deg == 2) {
+        const double a = c_in[0], b = c_in[1], c = c_in[2], D = b * b - 4 * a * c, sD = sqrt(fabs(D));
+        if (D >= 0) {
+            if (b >= 0) { re[0] = (-b - sD) / (2.0 * a); re[1] = (2.0 * c) / (-b - sD); }
+            else { re[0] = (2.0 * c) / (-b + sD); re[1] = (-b + sD) / (2.0 * a); }
+        } else { re[0] = re[1] = -b / (2.0 * a); }
+        return 2;
+    }
+    /* Aberth-Ehrlich on the monic polynomial, complex arithmetic by hand */
+    double m[5], zr[4], zi[4];
+    for (int i = 0; i <= deg; i++) m[i] = c_in[i] / c_in[0];
+    double rad = 0.0;
+    for (int i = 1; i <= deg; i++) { const double t = pow(fabs(m[i]), 1.0 / i); if (t > rad) rad = t; }
+    if (rad == 0.0) { for (int i = 0; i < deg; i++) re[i] = 0.0; return deg; }
+    for (int i = 0; i < deg; i++) { const double th = 2.0 * 3.14159265358979323846 * i / deg + 0.4; zr[i] = rad * cos(th); zi[i] = rad * sin(th); }
+    for (int it = 0; it < 200; it++) {
+        double worst = 0.0;
+        for (int i = 0; i < deg; i++) {
+            double pr = 1.0, pi = 0.0, dr = 0.0, di = 0.0;   /* p(z) and p'(z) by Horner */
+            for (int k = 1; k <= deg; k++) {
+                const double ndr = dr * zr[i] - di * zi[i] + pr, ndi = dr * zi[i] + di * zr[i] + pi;
+                const double npr = pr * zr[i] - pi * zi[i] + m[k], npi = pr * zi[i] + pi * zr[i];
+                dr = ndr; di = ndi; pr = npr; pi = npi;
+            }
+            /* w = p/p' ; z -= w / (1 - w * sum_{j != i} 1/(z_i - z_j)) */
+            const double dd = dr * dr + di * di;
+            if (dd == 0.0) continue;
+            const double wr = (pr * dr + pi * di) / dd, wi = (pi * dr - pr * di) / dd;
+            double sr = 0.0, si = 0.0;
+            for (int j = 0; j < deg; j++) if (j != i) {
+                const double ar = zr[i] - zr[j], ai = zi[i] - zi[j], ad = ar * ar + ai * ai;
+                if (ad > 0.0) { sr += ar / ad; si -= ai / ad; }
+            }
+            const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr), qd = qr * qr + qi * qi;
+            const double cr = qd > 0.0 ? (wr * qr + wi * qi) / qd : wr, ci = qd > 0.0 ? (wi * qr - wr * qi) / qd : wi;
+            zr[i] -= cr; zi[i] -= ci;
+            const double mag = sqrt(cr * cr + ci * ci);
+            if (mag > worst) worst = mag;
+        }
+        if (worst <= 1e-15 * rad) break;
+    }
+    for (int i = 0; i < deg; i++) re[i] = zr[i];
+    return deg;
+}
+
+/* ceres MinimizePolynomial: the midpoint, the two ends and the derivative's roots inside [x_min, x_max] */
+static double minimize_polynomial(const double* c, int deg, double x_min, double x_max)
+{
+    double best_x = 0.5 * (x_min + x_max), best = poly_eval(c, deg, best_x);
+    const double v0 = poly_eval(c, deg, x_min);
+    if (v0 < best) { best = v0; best_x = x_min; }
+    const double v1 = poly_eval(c, deg, x_max);
+    if (v1 < best) { best = v1; best_x = x_max; }
+    if (deg <= 1) return best_x;
+    double d[6], re[4];
+    for (int i = 0; i < deg; i++) d[i] = (deg - i) * c[i];
+    const int nr = polynomial_root_real_parts(d, deg - 1, re);
+    for (int i = 0; i < nr; i++) {
+        if (re[i] < x_min || re[i] > x_max) continue;
+        const double v = poly_eval(c, deg, re[i]);
+        if (v < best) { best = v; best_x = re[i]; }
+    }
+    return best_x;
+}
+
+/* LineSearch::InterpolatingPolynomialMinimizingStepSize with CUBIC interpolation */
+static double ls_next_step(const ls_sample* lower, const ls_sample* previous, const ls_sample* current, double min_step, double max_step)
+{
+    if (!current->value_ok) return fmin(fmax(current->x * 0.5, min_step), max_step);
+    ls_sample s[3];
+    int n = 0;
+    s[n++] = *lower;
+    s[n++] = *current;
+    if (previous->value_ok) s[n++] = *previous;
+    double coef[6];
+    const int deg = find_interpolating_polynomial(s, n, coef);
+    return minimize_polynomial(coef, deg, min_step, max_step);
+}
+
+/* LineSearchFunction::Evaluate at step size a: x+ = Plus(x, a delta) (points projected onto the box), cost and
+ * direction . gradient there */
+static void ls_evaluate(ws_t* w, const double* cams, const double* pts, double a, ls_sample* out, double* r, double* jc, double* jp)
+{
+    out->x = a; out->value_ok = 0; out->gradient_ok = 0;
+    for (size_t i = 0; i < 6 * (size_t)w->n_cam; i++) w->xc[i] = cams[i] + a * w->dc[i];
+    for (size_t i = 0; i < 3 * (size_t)w->n_pt; i++) w->xp[i] = clampd(pts[i] + a * w->dp[i], w->opt->lower_bound, w->opt->upper_bound);
+    out->value = oracle_ba_linearize(w->n_obs, w->obs_cam, w->obs_pt, w->uv, w->xc, w->xp, w->pl, w->pr, w->fixed, w->opt->huber_delta,
+                                     r, jc, jp);
+    if (!isfinite(out->value)) return;
+    out->value_ok = 1;
+    double g = 0.0;
+#pragma omp parallel for reduction(+ : g) schedule(static)
+    for (int64_t k = 0; k < (int64_t)w->n_obs; k++) {
+        const double* d = w->dc + 6 * (size_t)w->obs_cam[k]; const double* e = w->dp + 3 * (size_t)w->obs_pt[k];
+        for (int i = 0; i < 4; i++) {
+            double m = jp[12 * (size_t)k + i * 3] * e[0] + jp[12 * (size_t)k + i * 3 + 1] * e[1] + jp[12 * (size_t)k + i * 3 + 2] * e[2];
+            for (int q = 0; q < 6; q++) m += jc[24 * (size_t)k + i * 6 + q] * d[q];
+            g += m * r[4 * (size_t)k + i];
+        }
+    }
+    out->gradient = g;
+    if (isfinite(g)) out->gradient_ok = 1;
+}
+
+/* ArmijoLineSearch::DoSearch from step size 1; returns the step size to scale delta by (1 when the search fails or the
+ * full step already satisfies the sufficient-decrease condition) and counts its iterations */
+static double armijo_line_search(ws_t* w, const double* cams, const double* pts, double x_cost, double g_dot_delta, double full_cost,
+                                 int* n_iterations)
+{
+    const double suff = 1e-4, max_contraction = 1e-3, min_contraction = 0.6, min_step_size = 1e-9;
+    const int max_iter = 20;
+    if (full_cost <= x_cost + suff * g_dot_delta * 1.0) return 1.0;    /* Evaluate(1.0) already satisfies Armijo */
+    double dmax = 0.0;   /* DirectionInfinityNorm */
+    for (size_t i = 0; i < 6 * (size_t)w->n_cam; i++) if (fabs(w->dc[i]) > dmax) dmax = fabs(w->dc[i]);
+    for (size_t i = 0; i < 3 * (size_t)w->n_pt; i++) if (fabs(w->dp[i]) > dmax) dmax = fabs(w->dp[i]);
+    double* r = (double*)malloc(sizeof(double) * 4 * (size_t)w->n_obs);
+    double* jc = (double*)malloc(sizeof(double) * 24 * (size_t)w->n_obs);
+    double* jp = (double*)malloc(sizeof(double) * 12 * (size_t)w->n_obs);
+    if (!r || !jc || !jp) { free(r); free(jc); free(jp); return 1.0; }
+    ls_sample initial = {0.0, x_cost, g_dot_delta, 1, 1}, previous = {0.0, 0.0, 0.0, 0, 0}, current;
+    ls_evaluate(w, cams, pts, 1.0, &current, r, jc, jp);
+    double result = 1.0;
+    int iters = 0;
+    while (!current.value_ok || current.value > x_cost + suff * g_dot_delta * current.x) {
+        iters++;
+        if (iters >= max_iter) { result = 1.0; goto done; }                       /* search failed: delta untouched */
+        const double step = ls_next_step(&initial, &previous, &current, max_contraction * current.x, min_contraction * current.x);
+        if (step * dmax < min_step_size) { result = 1.0; goto done; }
+        previous = current;
+        ls_evaluate(w, cams, pts, step, &current, r, jc, jp);
+    }
+    result = current.x;
+done:
+    *n_iterations += iters;
+    free(r); free(jc); free(jp);
+    return result;
+}
+
 int oracle_ba_solve(uint32_t n_cam, uint32_t n_pt, uint32_t n_obs,
                     const uint32_t* obs_cam, const uint32_t* obs_pt, const float* obs_uv,
                     double* cams, double* pts, const double* pl, const double* pr,
@@ -779,11 +980,19 @@ int oracle_ba_solve(uint32_t n_cam, uint32_t n_pt, uint32_t n_obs,
         invalid_run = 0; it.valid = 1;
         double step_norm, x_norm;
         make_candidate(&w, cams, pts, &step_norm, &x_norm);
-        const double cand = oracle_ba_cost(n_obs, obs_cam, obs_pt, obs_uv, w.xc, w.xp, pl, pr, opt->huber_delta);
+        double cand = oracle_ba_cost(n_obs, obs_cam, obs_pt, obs_uv, w.xc, w.xp, pl, pr, opt->huber_delta);
+        /* bounded problem: DoLineSearch along the projected step before the candidate is evaluated; on success delta is
+           scaled by the step size found (the model cost change stays the full step's) */
+        {
+            const double a = armijo_line_search(&w, cams, pts, x_cost, gradient_dot_step(&w), cand, &armijo);
+            if (a != 1.0) {
+                for (size_t i = 0; i < 6 * (size_t)n_cam; i++) w.dc[i] *= a;
+                for (size_t i = 0; i < 3 * (size_t)n_pt; i++) w.dp[i] *= a;
+                make_candidate(&w, cams, pts, &step_norm, &x_norm);
+                cand = oracle_ba_cost(n_obs, obs_cam, obs_pt, obs_uv, w.xc, w.xp, pl, pr, opt->huber_delta);
+            }
+        }
         it.candidate_cost = cand; it.step_norm = step_norm;
-        /* Ceres runs an Armijo search (sufficient decrease 1e-4) on bounded problems before evaluating
-           the step; it leaves the step untouched iff this holds.  Count the iterations where it does not. */
-        if (!(cand <= x_cost + 1e-4 * gradient_dot_step(&w))) armijo++;
         if (opt->check_termination) {
             if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
                 if (log) log[iterations] = it;
@@ -818,7 +1027,7 @@ int oracle_ba_solve(uint32_t n_cam, uint32_t n_pt, uint32_t n_obs,
     if (summary) {
         summary->initial_cost = initial_cost; summary->final_cost = x_cost;
         summary->iterations = iterations; summary->accepted = accepted; summary->termination = term;
-        summary->armijo_violations = armijo;
+        summary->line_search_steps = armijo;
         summary->solve_seconds = now_sec() - t0; summary->setup_seconds = t0 - t_setup;
     }
     ws_free(&w);

@@ -71,7 +71,7 @@ typedef struct oracle_ba_summary {
     int32_t iterations;          /* LM iterations executed (accepted + rejected + invalid) */
     int32_t accepted;
     int32_t termination;
-    int32_t armijo_violations;   /* iterations where Ceres' bounded-problem line search would have shortened the step */
+    int32_t line_search_steps;   /* Solver::Summary::num_line_search_steps: iterations of the bounded-problem Armijo search */
     double  solve_seconds;       /* wall time of the LM loop only */
     double  setup_seconds;       /* index construction */
 } oracle_ba_summary;

@@ -33,7 +33,9 @@ enum {
     SC_SCHUR_STATUS = 16,                             // rank-local; spread through the candidate cost (launch_status_poison);
                                                       // next to the solver's slots: one memset clears all four per iteration
     SC_GATE = 17,                                     // 1: the device accepted the step and has linearised at the candidate
-    SC_COUNT = 18
+    SC_LS_COST = 18, SC_LS_DIR = 19, SC_LS_STEP2 = 20,   // line search trial: cost, direction . gradient, |x+ - x|^2 over the points
+    SC_LS_DMAX = 21,                                  // max |delta_i| (LineSearchFunction::DirectionInfinityNorm)
+    SC_COUNT = 22
 };
 
 struct Tile {      // one workgroup of ba_linearize / ba_cost
@@ -115,11 +117,12 @@ void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clea
 void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cam5, uint32_t n_cam5, double* out_cam5,
                       const double* cost_part, uint32_t n_cost, double* out_cost, double* gate, const double* status, double x_cost,
                       double min_relative_decrease, int gate_enabled, double stop_vote, double* pub_src, int n_pub, int clear_first,
-                      int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq);
+                      int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq, int armijo_in_gate = 1);
 // Multi-rank jobs: the acceptance test and the publication AFTER the step scalars were summed over the ranks - the same
 // test on the same operands as launch_step_sums applies on one rank, read from the scalar slots (scal = the SC_* array)
 void launch_gate_publish(hipStream_t s, double* scal, double x_cost, double min_relative_decrease, int gate_enabled, double* pub_src,
-                         int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq);
+                         int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq,
+                         int armijo_in_gate = 1);
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
@@ -140,6 +143,21 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
 // Multi-rank jobs: a rank whose point elimination failed (SC_SCHUR_STATUS) turns its share of the candidate cost
 // into +inf before the scalars are summed, so every rank sees a non-finite candidate and rejects the step alike.
 void launch_status_poison(hipStream_t s, double* scal);
+
+// ---- Ceres' line search on bounded problems (TrustRegionMinimizer::DoLineSearch; see run_lm) ----------------------------
+// trial point x+ = Plus(x, a delta): cameras x + a dc, points projected onto the box; ls_part[block][2] = {|x+ - x|^2 of the
+// block's points, max |delta_i| of the block}
+void launch_ls_candidate(hipStream_t s, uint32_t n_cam, uint32_t n_pt, const double* cams, const double* pts, const double* dc_full,
+                         const double* dp, double a, double bound_lo, double bound_hi, double* cams_out, double* pts_out, double* ls_part);
+inline uint32_t ls_candidate_blocks(uint32_t n_pt) { return (n_pt * 3 + 255) / 256 + 1; }
+// cost and direction . gradient at the trial point (campre_c, pts_c = its pose table and points; the direction is the FULL
+// step dc_full / dp): per tile [rho sum, sum of r~^T (J~_c dc + J~_p dp)] into tile_part2[tile][2]
+void launch_ls_eval(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt, const double* campre_c,
+                    const double* pts_c, const double* dc_full, const double* dp, const int32_t* cam_free, const Proj& P, double delta,
+                    double* tile_part2);
+// the sums of a trial into scal[SC_LS_COST .. SC_LS_DMAX]; host_dst != NULL: then the publication (see launch_publish)
+void launch_ls_sums(hipStream_t s, const double* tile_part2, uint32_t n_tiles, const double* ls_part, uint32_t n_ls_part, double* scal,
+                    double* pub_src, int n_pub, double* host_dst, unsigned long long* host_seq, unsigned long long seq);
 // dst[i] = src[i], i < n; either side may be pinned host memory mapped into the device (host-collective staging)
 void launch_copy_f64(hipStream_t s, double* dst, const double* src, uint64_t n);
 // *host_seq = seq (pinned host memory) after everything enqueued before it has completed

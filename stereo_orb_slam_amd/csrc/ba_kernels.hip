@@ -239,6 +239,8 @@ struct StepGate {   // the acceptance test of the LM loop for ba_step_sums_kerne
     const double* status;    // scal + SC_LIN_ITERS: [2] = SC_LIN_STATUS, [3] = SC_SCHUR_STATUS
     double x_cost, min_relative_decrease;
     int enabled;
+    int armijo;              // also require the sufficient-decrease condition of the bounded-problem line search (the host
+                             // shortens the step when it fails, so the candidate linearised behind the gate would be the wrong one)
 };
 
 struct Publish {   // optional tail of a one-workgroup kernel: n <= 64 doubles to pinned host memory, then a sequence number;
@@ -353,8 +355,9 @@ __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __rest
         // the same word and follows it).  Same operands and operations as run_lm.
         __syncthreads();
         if (threadIdx.x == 0) {
-            const double mcc = fin[0] + fin[6], cand = fin[5];
-            const bool ok = sg.status[2] == 0.0 && sg.status[3] == 0.0 && isfinite(mcc) && isfinite(cand) && mcc > 0.0;
+            const double mcc = fin[0] + fin[6], cand = fin[5], gdot = fin[3] + fin[9];
+            const bool ok = sg.status[2] == 0.0 && sg.status[3] == 0.0 && isfinite(mcc) && isfinite(cand) && mcc > 0.0 &&
+                            (!sg.armijo || cand <= sg.x_cost + 1e-4 * gdot);
             *sg.gate = (sg.enabled && ok && (sg.x_cost - cand) / mcc > sg.min_relative_decrease) ? 1.0 : 0.0;
         }
     }
@@ -363,11 +366,13 @@ __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __rest
 
 // The acceptance test on scalars that were summed over the ranks after ba_step_sums wrote them, then the publication.
 __global__ __launch_bounds__(64) void ba_gate_publish_kernel(double* __restrict__ scal, const double x_cost,
-                                                              const double min_relative_decrease, const int enabled, const Publish pb)
+                                                              const double min_relative_decrease, const int enabled, const int armijo,
+                                                              const Publish pb)
 {
     if (threadIdx.x == 0) {
-        const double mcc = scal[SC_MCC_PTS] + scal[SC_MCC_CAM], cand = scal[SC_CAND_COST];
-        const bool ok = scal[SC_LIN_STATUS] == 0.0 && scal[SC_SCHUR_STATUS] == 0.0 && isfinite(mcc) && isfinite(cand) && mcc > 0.0;
+        const double mcc = scal[SC_MCC_PTS] + scal[SC_MCC_CAM], cand = scal[SC_CAND_COST], gdot = scal[SC_GDOT_PTS] + scal[SC_GDOT_CAM];
+        const bool ok = scal[SC_LIN_STATUS] == 0.0 && scal[SC_SCHUR_STATUS] == 0.0 && isfinite(mcc) && isfinite(cand) && mcc > 0.0 &&
+                        (!armijo || cand <= x_cost + 1e-4 * gdot);
         scal[SC_GATE] = (enabled && ok && (x_cost - cand) / mcc > min_relative_decrease) ? 1.0 : 0.0;
     }
     publish_tail(pb);
@@ -1199,17 +1204,18 @@ void launch_publish(hipStream_t s, double* src, int n, int clear_first, int clea
 void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* out5, const double* cam5, uint32_t n_cam5, double* out_cam5,
                       const double* cost_part, uint32_t n_cost, double* out_cost, double* gate, const double* status, double x_cost,
                       double min_relative_decrease, int gate_enabled, double stop_vote, double* pub_src, int n_pub, int clear_first,
-                      int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+                      int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq, int armijo_in_gate)
 {
     hipLaunchKernelGGL(ba_step_sums_kernel, dim3(1), dim3(1024), 0, s, part5, n5, out5, cam5, n_cam5, out_cam5, cost_part, n_cost, out_cost,
-                       StepGate{gate, status, x_cost, min_relative_decrease, gate_enabled}, stop_vote,
+                       StepGate{gate, status, x_cost, min_relative_decrease, gate_enabled, armijo_in_gate}, stop_vote,
                        Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
 }
 
 void launch_gate_publish(hipStream_t s, double* scal, double x_cost, double min_relative_decrease, int gate_enabled, double* pub_src,
-                         int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+                         int n_pub, int clear_first, int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq,
+                         int armijo_in_gate)
 {
-    hipLaunchKernelGGL(ba_gate_publish_kernel, dim3(1), dim3(64), 0, s, scal, x_cost, min_relative_decrease, gate_enabled,
+    hipLaunchKernelGGL(ba_gate_publish_kernel, dim3(1), dim3(64), 0, s, scal, x_cost, min_relative_decrease, gate_enabled, armijo_in_gate,
                        Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
 }
 
@@ -1264,6 +1270,134 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
         hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(schur_threads(32)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
                            q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
     }
+}
+
+// ---- line search trial (TrustRegionMinimizer::DoLineSearch on bounded problems; run only when the full step fails the
+// sufficient-decrease condition) ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_ls_candidate_kernel(uint32_t n_cam, uint32_t n_pt, const double* __restrict__ cams,
+                                                              const double* __restrict__ pts, const double* __restrict__ dc_full,
+                                                              const double* __restrict__ dp, const double a, const double lo, const double hi,
+                                                              double* __restrict__ cams_out, double* __restrict__ pts_out,
+                                                              double* __restrict__ ls_part)
+{
+    __shared__ double red[8];
+    double st2 = 0.0, dmax = 0.0;
+    const uint32_t nb_pt = (n_pt * 3 + 255) / 256;
+    if (blockIdx.x < nb_pt) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n_pt * 3) {
+            const double x = pts[i], d = dp[i];
+            const double xn = fmin(fmax(x + a * d, lo), hi);   // ParameterBlock::Plus projects onto the bounds
+            pts_out[i] = xn;
+            st2 = (xn - x) * (xn - x);
+            dmax = fabs(d);
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < n_cam * 6; i += 256) {
+            const double d = dc_full[i];
+            cams_out[i] = cams[i] + a * d;
+            dmax = fmax(dmax, fabs(d));
+        }
+    }
+    st2 = wave_sum(st2); dmax = wave_max(dmax);
+    if (threadIdx.x % kWave == 0) { red[threadIdx.x / kWave] = st2; red[4 + threadIdx.x / kWave] = dmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ls_part[2 * (size_t)blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        ls_part[2 * (size_t)blockIdx.x + 1] = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    }
+}
+
+__global__ __launch_bounds__(kTileThreads) void ba_ls_eval_kernel(
+    const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
+    const double* __restrict__ campre_c, const double* __restrict__ pts_c, const double* __restrict__ dc_full,
+    const double* __restrict__ dp, const int32_t* __restrict__ cam_free, const Proj P, const double delta,
+    double* __restrict__ tile_part2)
+{
+    __shared__ double red[2 * (kTileThreads / kWave)];
+    const Tile t = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    PosePre pr;
+    pose_load(campre_c + kPoseStride * (size_t)t.cam, pr);
+    const bool fixed = cam_free[t.cam] < 0;
+    // direction of the camera block in camera-frame terms: J_c dc = A (D dc_rot + dc_t), D = -[v]x M  =>  D dc_rot = (M dc_rot) x v
+    const double* dcam = dc_full + 6 * (size_t)t.cam;
+    double w[3] = {0.0, 0.0, 0.0}, dt[3] = {0.0, 0.0, 0.0};
+    if (!fixed) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            w[i] = pr.M[i * 3] * dcam[0] + pr.M[i * 3 + 1] * dcam[1] + pr.M[i * 3 + 2] * dcam[2];
+            dt[i] = dcam[3 + i];
+        }
+    }
+    double rho = 0.0, dir = 0.0;
+    for (uint32_t o = tid; o < t.count; o += kTileThreads) {
+        const size_t k = (size_t)t.start + o;
+        const uint32_t p = obs_pt[k];
+        const double x[3] = {pts_c[3 * (size_t)p], pts_c[3 * (size_t)p + 1], pts_c[3 * (size_t)p + 2]};
+        const double e[3] = {dp[3 * (size_t)p], dp[3 * (size_t)p + 1], dp[3 * (size_t)p + 2]};
+        double r[4], am[12], D[9];
+        rho += residual_ad(pr, x, uv[k], P, delta, r, am, D);
+        double v[3];
+        compact_v(pr.R, pr.small, x, v);
+        double u[3] = {w[1] * v[2] - w[2] * v[1] + dt[0], w[2] * v[0] - w[0] * v[2] + dt[1], w[0] * v[1] - w[1] * v[0] + dt[2]};
+#pragma unroll
+        for (int i = 0; i < 3; i++) u[i] += pr.R[i * 3] * e[0] + pr.R[i * 3 + 1] * e[1] + pr.R[i * 3 + 2] * e[2];   // J_p dp = A R dp
+#pragma unroll
+        for (int i = 0; i < 4; i++) dir += r[i] * (am[i * 3] * u[0] + am[i * 3 + 1] * u[1] + am[i * 3 + 2] * u[2]);
+    }
+    rho = wave_sum(rho); dir = wave_sum(dir);
+    if (tid % kWave == 0) { red[2 * (tid / kWave)] = rho; red[2 * (tid / kWave) + 1] = dir; }
+    __syncthreads();
+    if (tid < 2) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < kTileThreads / kWave; q++) s += red[2 * q + tid];
+        tile_part2[2 * (size_t)blockIdx.x + tid] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void ba_ls_sums_kernel(const double* __restrict__ tile_part2, uint32_t n_tiles,
+                                                           const double* __restrict__ ls_part, uint32_t n_ls_part,
+                                                           double* __restrict__ scal, const Publish pb)
+{
+    __shared__ double red[16 * 4];
+    double c = 0.0, d = 0.0, s2 = 0.0, mx = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024) { c += tile_part2[2 * (size_t)i]; d += tile_part2[2 * (size_t)i + 1]; }
+    for (uint32_t i = threadIdx.x; i < n_ls_part; i += 1024) { s2 += ls_part[2 * (size_t)i]; mx = fmax(mx, ls_part[2 * (size_t)i + 1]); }
+    c = wave_sum(c); d = wave_sum(d); s2 = wave_sum(s2); mx = wave_max(mx);
+    if (threadIdx.x % kWave == 0) { double* o = red + 4 * (threadIdx.x / kWave); o[0] = c; o[1] = d; o[2] = s2; o[3] = mx; }
+    __syncthreads();
+    static_assert(SC_LS_DIR == SC_LS_COST + 1 && SC_LS_STEP2 == SC_LS_COST + 2 && SC_LS_DMAX == SC_LS_COST + 3, "line-search slots");
+    if (threadIdx.x < 4) {
+        double a = 0.0;
+        for (int q = 0; q < 16; q++) a = threadIdx.x == 3 ? fmax(a, red[4 * q + 3]) : a + red[4 * q + threadIdx.x];
+        scal[SC_LS_COST + threadIdx.x] = threadIdx.x == 0 ? 0.5 * a : a;
+    }
+    publish_tail(pb);
+}
+
+void launch_ls_candidate(hipStream_t s, uint32_t n_cam, uint32_t n_pt, const double* cams, const double* pts, const double* dc_full,
+                         const double* dp, double a, double bound_lo, double bound_hi, double* cams_out, double* pts_out, double* ls_part)
+{
+    hipLaunchKernelGGL(ba_ls_candidate_kernel, dim3(ls_candidate_blocks(n_pt)), dim3(256), 0, s, n_cam, n_pt, cams, pts, dc_full, dp, a,
+                       bound_lo, bound_hi, cams_out, pts_out, ls_part);
+}
+
+void launch_ls_eval(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt, const double* campre_c,
+                    const double* pts_c, const double* dc_full, const double* dp, const int32_t* cam_free, const Proj& P, double delta,
+                    double* tile_part2)
+{
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(ba_ls_eval_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre_c, pts_c, dc_full, dp, cam_free, P,
+                       delta, tile_part2);
+}
+
+void launch_ls_sums(hipStream_t s, const double* tile_part2, uint32_t n_tiles, const double* ls_part, uint32_t n_ls_part, double* scal,
+                    double* pub_src, int n_pub, double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+{
+    hipLaunchKernelGGL(ba_ls_sums_kernel, dim3(1), dim3(1024), 0, s, tile_part2, n_tiles, ls_part, n_ls_part, scal,
+                       Publish{pub_src, host_dst, host_seq, seq, n_pub, 0, 0});
 }
 
 // Staging of the host-collective leg: device <-> pinned host memory by a kernel, in stream order with everything else

@@ -9,6 +9,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <complex>
 #include <cstdlib>
 #include <iterator>
 #include <memory>
@@ -125,6 +126,7 @@ struct soslam_ba {
     bool collective() const { return rccl != nullptr || allreduce != nullptr || host_allreduce != nullptr; }
     bool stop_agreed = false;           // multi-rank: some rank voted to end the solve (time limit) in the last iteration
     DevBuf<double> gather;              // soslam_ba_get_state_global: all ranks' points
+    DevBuf<double> ls_tile, ls_part;    // line-search trial: per-tile {rho, direction . gradient}, per-block {|step|^2, max |delta|}
 
     // trust region
     double radius = 0.0, decrease_factor = 2.0, x_cost = 0.0;
@@ -974,6 +976,200 @@ StepScalars read_scalars(const soslam_ba* h)
     return r;
 }
 
+// ---- Ceres' line search on bounded problems -------------------------------------------------------------------------
+// /root/reference/src/bundle_adjuster.cpp:104-108 bounds every point coordinate, so Ceres treats the problem as constrained:
+// every valid trust-region step goes through TrustRegionMinimizer::DoLineSearch before its candidate is evaluated - an
+// Armijo search (sufficient decrease 1e-4) from step size 1 along the step, trial points projected onto the box, CUBIC
+// interpolation on cost and directional derivative (both evaluated at every trial), contraction within [1e-3, 0.6] of the
+// last step size, at most 20 iterations, step sizes below 1e-9 / |delta|_inf given up; on success the step is scaled by
+// the size found, on failure it is left alone; the model cost change stays that of the full step.  The host runs the
+// search (a handful of scalars per trial), the device evaluates the trials (ba_ls_candidate / ba_ls_eval / ba_ls_sums).
+// The first trial - step size 1 - is the candidate the iteration has already evaluated, so the search costs nothing
+// unless that candidate fails the sufficient-decrease test.
+struct LsSample { double x = 0.0, value = 0.0, gradient = 0.0; bool value_ok = false, gradient_ok = false; };
+
+double ls_polyval(const std::vector<double>& c, double x)   // c[0] x^n + ... + c[n]
+{
+    double v = 0.0;
+    for (double ci : c) v = v * x + ci;
+    return v;
+}
+
+// polynomial through the samples' values and gradients (Ceres FindInterpolatingPolynomial), highest power first
+std::vector<double> ls_interpolate(const std::vector<LsSample>& smp)
+{
+    int nc = 0;
+    for (const LsSample& q : smp) nc += (q.value_ok ? 1 : 0) + (q.gradient_ok ? 1 : 0);
+    const int deg = nc - 1;
+    std::vector<std::vector<double>> a((size_t)nc, std::vector<double>((size_t)nc + 1, 0.0));
+    int row = 0;
+    for (const LsSample& q : smp) {
+        if (q.value_ok) {
+            for (int j = 0; j <= deg; j++) a[(size_t)row][(size_t)j] = std::pow(q.x, deg - j);
+            a[(size_t)row][(size_t)nc] = q.value; row++;
+        }
+        if (q.gradient_ok) {
+            for (int j = 0; j < deg; j++) a[(size_t)row][(size_t)j] = (deg - j) * std::pow(q.x, deg - j - 1);
+            a[(size_t)row][(size_t)nc] = q.gradient; row++;
+        }
+    }
+    for (int k = 0; k < nc; k++) {   // elimination with row pivoting
+        int piv = k;
+        for (int r = k + 1; r < nc; r++) if (std::fabs(a[(size_t)r][(size_t)k]) > std::fabs(a[(size_t)piv][(size_t)k])) piv = r;
+        std::swap(a[(size_t)k], a[(size_t)piv]);
+        if (a[(size_t)k][(size_t)k] == 0.0) continue;
+        for (int r = k + 1; r < nc; r++) {
+            const double f = a[(size_t)r][(size_t)k] / a[(size_t)k][(size_t)k];
+            for (int j = k; j <= nc; j++) a[(size_t)r][(size_t)j] -= f * a[(size_t)k][(size_t)j];
+        }
+    }
+    std::vector<double> c((size_t)nc, 0.0);
+    for (int k = nc - 1; k >= 0; k--) {
+        double v = a[(size_t)k][(size_t)nc];
+        for (int j = k + 1; j < nc; j++) v -= a[(size_t)k][(size_t)j] * c[(size_t)j];
+        c[(size_t)k] = a[(size_t)k][(size_t)k] != 0.0 ? v / a[(size_t)k][(size_t)k] : 0.0;
+    }
+    return c;
+}
+
+// real parts of all roots (Ceres evaluates the polynomial at the real part of complex roots too)
+std::vector<double> ls_root_real_parts(std::vector<double> c)
+{
+    while (c.size() > 1 && c.front() == 0.0) c.erase(c.begin());
+    const int deg = (int)c.size() - 1;
+    if (deg <= 0) return {};
+    if (deg == 1) return {-c[1] / c[0]};
+    if (deg == 2) {
+        const double a = c[0], b = c[1], cc = c[2], D = b * b - 4 * a * cc, sD = std::sqrt(std::fabs(D));
+        if (D >= 0) return b >= 0 ? std::vector<double>{(-b - sD) / (2.0 * a), (2.0 * cc) / (-b - sD)}
+                                  : std::vector<double>{(2.0 * cc) / (-b + sD), (-b + sD) / (2.0 * a)};
+        return {-b / (2.0 * a), -b / (2.0 * a)};
+    }
+    // Aberth-Ehrlich iteration on the monic polynomial
+    using cd = std::complex<double>;
+    std::vector<double> m((size_t)deg + 1);
+    for (int i = 0; i <= deg; i++) m[(size_t)i] = c[(size_t)i] / c[0];
+    double rad = 0.0;
+    for (int i = 1; i <= deg; i++) rad = std::max(rad, std::pow(std::fabs(m[(size_t)i]), 1.0 / i));
+    if (rad == 0.0) return std::vector<double>((size_t)deg, 0.0);
+    std::vector<cd> z((size_t)deg);
+    for (int i = 0; i < deg; i++) z[(size_t)i] = std::polar(rad, 2.0 * 3.14159265358979323846 * i / deg + 0.4);
+    for (int it = 0; it < 200; it++) {
+        double worst = 0.0;
+        for (int i = 0; i < deg; i++) {
+            cd pv(1.0, 0.0), dv(0.0, 0.0);
+            for (int k = 1; k <= deg; k++) { dv = dv * z[(size_t)i] + pv; pv = pv * z[(size_t)i] + m[(size_t)k]; }
+            if (dv == cd(0.0, 0.0)) continue;
+            const cd w = pv / dv;
+            cd sum(0.0, 0.0);
+            for (int j = 0; j < deg; j++) if (j != i && z[(size_t)i] != z[(size_t)j]) sum += 1.0 / (z[(size_t)i] - z[(size_t)j]);
+            const cd q = 1.0 - w * sum;
+            const cd corr = q == cd(0.0, 0.0) ? w : w / q;
+            z[(size_t)i] -= corr;
+            worst = std::max(worst, std::abs(corr));
+        }
+        if (worst <= 1e-15 * rad) break;
+    }
+    std::vector<double> re;
+    for (const cd& q : z) re.push_back(q.real());
+    return re;
+}
+
+// Ceres MinimizePolynomial on [x_min, x_max]: midpoint, both ends, the derivative's roots inside
+double ls_minimize(const std::vector<double>& c, double x_min, double x_max)
+{
+    double best_x = 0.5 * (x_min + x_max), best = ls_polyval(c, best_x);
+    for (double x : {x_min, x_max}) { const double v = ls_polyval(c, x); if (v < best) { best = v; best_x = x; } }
+    const int deg = (int)c.size() - 1;
+    if (deg <= 1) return best_x;
+    std::vector<double> d((size_t)deg);
+    for (int i = 0; i < deg; i++) d[(size_t)i] = (deg - i) * c[(size_t)i];
+    for (double r : ls_root_real_parts(d)) {
+        if (r < x_min || r > x_max) continue;
+        const double v = ls_polyval(c, r);
+        if (v < best) { best = v; best_x = r; }
+    }
+    return best_x;
+}
+
+// one trial of the search: candidate x+ = Plus(x, a delta) into cams[cur ^ 1] / pts[cur ^ 1] / campre_c, its cost,
+// direction . gradient, |x+ - x|^2 and |delta|_inf (summed / maximised over ranks) into h->host_scal[SC_LS_*]
+int ls_evaluate(soslam_ba* h, double a)
+{
+    hipStream_t s = h->stream;
+    SOSLAM_CHECK(h->ls_tile.alloc(2 * (size_t)std::max<uint32_t>(h->n_tiles, 1)));
+    SOSLAM_CHECK(h->ls_part.alloc(2 * (size_t)ls_candidate_blocks(h->n_pt)));
+    launch_ls_candidate(s, h->n_cam, h->n_pt, h->cams[h->cur].p, h->pts[h->cur].p, h->dc_full.p, h->dp.p, a, h->opt.lower_bound,
+                        h->opt.upper_bound, h->cams[h->cur ^ 1].p, h->pts[h->cur ^ 1].p, h->ls_part.p);
+    launch_pose_prepare(s, h->n_cam, h->cams[h->cur ^ 1].p, h->campre_c.p);
+    launch_ls_eval(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->dc_full.p, h->dp.p, h->cam_free.p,
+                   h->proj, h->opt.huber_delta, h->ls_tile.p);
+    const unsigned long long seq = ++h->publish_seq;
+    if (!h->collective()) {
+        launch_ls_sums(s, h->ls_tile.p, h->n_tiles, h->ls_part.p, ls_candidate_blocks(h->n_pt), h->scalp(), h->tail(), 4 + SC_COUNT, h->host_raw,
+                       h->host_seq, seq);
+    } else {
+        launch_ls_sums(s, h->ls_tile.p, h->n_tiles, h->ls_part.p, ls_candidate_blocks(h->n_pt), h->scalp(), nullptr, 0, nullptr, nullptr, 0);
+        SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_LS_COST, 3, SOSLAM_REDUCE_SUM));
+        SOSLAM_CHECK(do_allreduce(h, h->scalp() + SC_LS_DMAX, 1, SOSLAM_REDUCE_MAX));
+        launch_publish(s, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 0, h->host_raw, h->host_seq, seq);
+    }
+    return wait_host_seq(h, h->host_seq, seq);
+}
+
+// ArmijoLineSearch::DoSearch from step size 1 (whose cost is already known).  Out: step size (1 = delta untouched), and when
+// it is < 1 the accepted trial's cost and |x+ - x| (the candidate buffers then hold that trial).
+int line_search(soslam_ba* h, const StepScalars& sc, double* step_size, double* cand_cost, double* step_norm, int* n_iterations)
+{
+    constexpr double kSufficientDecrease = 1e-4, kMaxContraction = 1e-3, kMinContraction = 0.6, kMinStepSize = 1e-9;
+    constexpr int kMaxIterations = 20;
+    *step_size = 1.0;
+    if (sc.cand_cost <= sc.x_cost + kSufficientDecrease * sc.gdot) return SOSLAM_OK;   // the full step satisfies Armijo
+    const double step2_cam_full = h->host_scal[SC_STEP2_CAM];
+    LsSample initial, previous, current;
+    initial.x = 0.0; initial.value = sc.x_cost; initial.gradient = sc.gdot; initial.value_ok = initial.gradient_ok = true;
+    auto evaluate = [&](double a, LsSample& out) -> int {
+        SOSLAM_CHECK(ls_evaluate(h, a));
+        out = LsSample{};
+        out.x = a;
+        out.value = h->host_scal[SC_LS_COST];
+        out.gradient = h->host_scal[SC_LS_DIR];
+        out.value_ok = std::isfinite(out.value);
+        out.gradient_ok = out.value_ok && std::isfinite(out.gradient);
+        return SOSLAM_OK;
+    };
+    SOSLAM_CHECK(evaluate(1.0, current));     // Ceres evaluates cost AND gradient at the first trial (CUBIC interpolation)
+    const double dmax = h->host_scal[SC_LS_DMAX];
+    int iters = 0;
+    bool found = true;
+    while (!current.value_ok || current.value > sc.x_cost + kSufficientDecrease * sc.gdot * current.x) {
+        iters++;
+        if (iters >= kMaxIterations) { found = false; break; }
+        double step;
+        const double lo = kMaxContraction * current.x, hi = kMinContraction * current.x;
+        if (!current.value_ok) {
+            step = std::min(std::max(current.x * 0.5, lo), hi);
+        } else {
+            std::vector<LsSample> smp{initial, current};
+            if (previous.value_ok) smp.push_back(previous);
+            step = ls_minimize(ls_interpolate(smp), lo, hi);
+        }
+        if (step * dmax < kMinStepSize) { found = false; break; }
+        previous = current;
+        SOSLAM_CHECK(evaluate(step, current));
+    }
+    *n_iterations += iters;
+    if (!found) {
+        // the search failed: Ceres leaves delta alone - the candidate buffers must hold the full step again
+        SOSLAM_CHECK(evaluate(1.0, current));
+        return SOSLAM_OK;
+    }
+    *step_size = current.x;
+    *cand_cost = current.value;
+    *step_norm = std::sqrt(h->host_scal[SC_LS_STEP2] + current.x * current.x * step2_cam_full);
+    return SOSLAM_OK;
+}
+
 // The Levenberg-Marquardt loop.  fixed_count >= 0: exactly that many iterations, no termination tests.
 int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
 {
@@ -1063,9 +1259,16 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         }
         h->invalid_run = 0;
         e.valid = 1;
+        // bounded problem: the line search along the projected step, before the candidate is judged (see line_search)
+        {
+            double a = 1.0, ls_cost = 0.0, ls_norm = 0.0;
+            int ls_iters = 0;
+            SOSLAM_CHECK(line_search(h, sc, &a, &ls_cost, &ls_norm, &ls_iters));
+            sum.line_search_steps += ls_iters;
+            if (a != 1.0) { sc.cand_cost = ls_cost; sc.step_norm = ls_norm; }
+        }
         e.candidate_cost = sc.cand_cost;
         e.step_norm = sc.step_norm;
-        if (!(sc.cand_cost <= sc.x_cost + 1e-4 * sc.gdot)) sum.armijo_violations++;
         if (check) {
             if (sc.step_norm <= o.parameter_tolerance * (sc.x_norm + o.parameter_tolerance)) {
                 h->log.push_back(e);

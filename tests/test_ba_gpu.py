@@ -193,7 +193,7 @@ def test_full_solve_config1_matches_oracle(gpu, oracle_lib, prob1, solver):
     # same accept/reject sequence and termination as the oracle's controller
     assert summ.iterations == osum.iterations and summ.termination == osum.termination
     assert [e.accepted for e in log] == [e.accepted for e in olog]
-    assert summ.armijo_violations == osum.armijo_violations
+    assert summ.line_search_steps == osum.line_search_steps
 
 
 def test_solve_reaches_scipy_minimum(gpu, golden_dir):
@@ -757,3 +757,24 @@ def test_one_step_is_bitwise_stable_while_another_process_uses_the_gpu(gpu, solv
             assert noise.poll() is None, "the second process must still have been running"
     finally:
         noise.wait(timeout=120)
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_line_search_on_the_bounded_problem(gpu, oracle_lib, prob1, solver):
+    """/root/reference/src/bundle_adjuster.cpp:104-108 bounds every point coordinate, so Ceres runs its Armijo line search on
+    every valid step before judging it (TrustRegionMinimizer::DoLineSearch; oracle/ba_oracle.c restates it).  The config-1
+    stand-in has iterations where the full step fails the sufficient-decrease test: the device path must shorten exactly
+    those steps, by the same factors - same number of search iterations, same cost after every iteration."""
+    ba, synth, L = gpu
+    ocams, opts_, osum, olog = _oracle_solve(oracle_lib, prob1, max_iterations=50, check_termination=0)
+    assert osum.line_search_steps > 0, "the stand-in no longer exercises the line search"
+    with ba.BundleAdjustment(ba.default_options(linear_solver=solver, max_iterations=50, check_termination=0)) as h:
+        h.load(prob1)
+        summ = h.solve()
+        cams, pts = h.get_state()
+        log = h.iteration_log()
+    assert summ.line_search_steps == osum.line_search_steps
+    assert [e.accepted for e in log] == [e.accepted for e in olog]
+    np.testing.assert_allclose([e.cost for e in log], [e.cost for e in olog], rtol=1e-7)
+    np.testing.assert_allclose([e.step_norm for e in log[1:]], [e.step_norm for e in olog[1:]], rtol=1e-5)
+    _compare_solutions(summ, cams, pts, osum, ocams, opts_)
