@@ -53,3 +53,20 @@ def test_malformed_dump_is_rejected(soslam, tmp_path):
         f.write("10\n1 2 3\n")
     with pytest.raises(ValueError):
         dump_io.read_dump(str(tmp_path), p.proj_l, p.proj_r)
+
+
+def test_oracle_backed_demo_runs_the_schedule(soslam, oracle_lib, tmp_path):
+    """The checker of the schedule parity test (tests/test_host_shim_gpu.py) on its own: the unchanged shim + demo sources
+    over the oracle (oracle/cabi_over_oracle.c) play the reference's schedule on a small map and reduce its cost."""
+    from stereo_orb_slam_amd import dump_io, synth
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "demo"], stdout=subprocess.DEVNULL)
+    p = synth.generate_ba(None, n_cam=8, n_pt=400, track_mode=1, track_len=4, spacing=0.9)
+    dump_io.write_dump(str(tmp_path / "in"), p)
+    os.makedirs(tmp_path / "out")
+    out = subprocess.run([os.path.join(ROOT, "oracle", "_build", "ba_demo_oracle"), str(tmp_path / "in"), str(tmp_path / "out"),
+                          "--schedule", "4", "--iters", "6", "--quiet"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    q = dump_io.read_dump(str(tmp_path / "out"), p.proj_l, p.proj_r)
+    c0 = oracle_lib.cost(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r)
+    c1 = oracle_lib.cost(p.obs_cam, p.obs_pt, p.obs_uv, q.poses_cw(), q.points_f64(), p.proj_l, p.proj_r)
+    assert c1 < 0.5 * c0
