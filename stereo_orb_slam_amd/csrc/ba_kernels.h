@@ -144,6 +144,32 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
 // into +inf before the scalars are summed, so every rank sees a non-finite candidate and rejects the step alike.
 void launch_status_poison(hipStream_t s, double* scal);
 
+// ---- structure-only problems (every camera constant: BundleAdjuster::Optimize(n-1, n), /root/reference/src/slam.cpp:123) ----
+// The problem decouples into independent 3-variable blocks under ONE trust region.  For problems of at most
+// kPointsOnlyMax points a single workgroup does a whole LM iteration in one launch: linearise every point at x (J_p^T J_p,
+// J_p^T r, cost), damp, solve, project the candidate onto the box, evaluate it, sum the step scalars, test acceptance,
+// publish - what the general path spreads over a dozen launches (no Schur complement, no camera system).
+constexpr uint32_t kPointsOnlyMax = 16384;
+struct PointsStepArgs {
+    uint32_t n_pt;
+    const uint32_t* pt_start; const uint32_t* pt_obs; const uint32_t* q_cam;
+    const float4* uv;
+    const double* campre;            // pose table of the (constant) cameras
+    const double* pts;               // x
+    double* pts_out;                 // candidate
+    double* dp;                      // full step (the line search's direction)
+    double* C; double* gp; double* sp; double* Cinv;
+    LmDiag lm;
+    double huber_delta, bound_lo, bound_hi;
+    int init_scale, jacobi;
+    double* scal;                    // the SC_* array
+    double* cost_x_out;              // where the host looks for the cost at x (the reduce payload's tail)
+    double x_cost, min_relative_decrease;
+    int gate_enabled;
+};
+void launch_points_step(hipStream_t s, const PointsStepArgs& a, const Proj& P, double* pub_src, int n_pub, int clear_first, int clear_n,
+                        double* host_dst, unsigned long long* host_seq, unsigned long long seq);
+
 // ---- Ceres' line search on bounded problems (TrustRegionMinimizer::DoLineSearch; see run_lm) ----------------------------
 // trial point x+ = Plus(x, a delta): cameras x + a dc, points projected onto the box; ls_part[block][2] = {|x+ - x|^2 of the
 // block's points, max |delta_i| of the block}

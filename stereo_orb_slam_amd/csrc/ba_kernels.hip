@@ -557,7 +557,19 @@ template <int TPW, int KB, int LD, int NA = TPW>
 __device__ __forceinline__ void schur_mfma_dispatch(int n_act, const double* const (&pa)[TPW], const double* const (&pb)[TPW],
                                                     schur_double4 (&acc)[TPW])
 {
-    if constexpr (NA >= 1) {
+    if constexpr (TPW > 6) {
+        // wide windows (ten tile slots per wave): one rolled loop with a wave-uniform test per tile - a body per tile
+        // count would cost more registers than the kernel has
+#pragma unroll 1
+        for (int k0 = 0; k0 < KB; k0 += 4) {
+            double av[TPW], bv[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; j++) { av[j] = pa[j][k0 * LD]; bv[j] = pb[j][k0 * LD]; }
+#pragma unroll
+            for (int j = 0; j < TPW; j++)
+                if (j < n_act) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], bv[j], acc[j], 0, 0, 0);
+        }
+    } else if constexpr (NA >= 1) {
         if (n_act == NA) schur_mfma_body<NA, TPW, KB, LD>(pa, pb, acc);
         else schur_mfma_dispatch<TPW, KB, LD, NA - 1>(n_act, pa, pb, acc);
     }
@@ -1270,6 +1282,106 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
         hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(schur_threads(32)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
                            q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
     }
+}
+
+// ---- structure-only LM iteration in one launch (see PointsStepArgs) -------------------------------------------------------
+__global__ __launch_bounds__(1024) void ba_points_step_kernel(const PointsStepArgs a, const Proj P, const Publish pb)
+{
+    __shared__ double red[16 * 8];
+    __shared__ double fin[8];
+    double cost_x = 0.0, cost_c = 0.0, mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
+    bool bad = false;
+    for (uint32_t p = threadIdx.x; p < a.n_pt; p += 1024) {
+        const double x[3] = {a.pts[3 * (size_t)p], a.pts[3 * (size_t)p + 1], a.pts[3 * (size_t)p + 2]};
+        // linearisation at x: J_p = A R per observation
+        double c[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        const uint32_t q0 = a.pt_start[p], q1 = a.pt_start[p + 1];
+        for (uint32_t q = q0; q < q1; q++) {
+            PosePre pr;
+            pose_load(a.campre + kPoseStride * (size_t)a.q_cam[q], pr);
+            double r[4], am[12], D[9];
+            cost_x += residual_ad(pr, x, a.uv[a.pt_obs[q]], P, a.huber_delta, r, am, D);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                double j[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) j[k] = am[i * 3] * pr.R[k] + am[i * 3 + 1] * pr.R[3 + k] + am[i * 3 + 2] * pr.R[6 + k];
+                c[0] += j[0] * j[0]; c[1] += j[0] * j[1]; c[2] += j[0] * j[2]; c[3] += j[1] * j[1]; c[4] += j[1] * j[2]; c[5] += j[2] * j[2];
+                g[0] += j[0] * r[i]; g[1] += j[1] * r[i]; g[2] += j[2] * r[i];
+            }
+        }
+        double sc[3];
+        if (a.init_scale) {
+            sc[0] = a.jacobi ? 1.0 / (1.0 + sqrt(c[0])) : 1.0; sc[1] = a.jacobi ? 1.0 / (1.0 + sqrt(c[3])) : 1.0;
+            sc[2] = a.jacobi ? 1.0 / (1.0 + sqrt(c[5])) : 1.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) a.sp[3 * (size_t)p + k] = sc[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) sc[k] = a.sp[3 * (size_t)p + k];
+        }
+        const double lam[3] = {point_lambda(c[0], sc[0], a.lm), point_lambda(c[3], sc[1], a.lm), point_lambda(c[5], sc[2], a.lm)};
+        const double m[6] = {c[0] + lam[0], c[1], c[2], c[3] + lam[1], c[4], c[5] + lam[2]};
+        double ci[6];
+        if (!sym3_inverse(m, ci)) bad = true;
+        const double e[3] = {-(ci[0] * g[0] + ci[1] * g[1] + ci[2] * g[2]), -(ci[1] * g[0] + ci[3] * g[1] + ci[4] * g[2]),
+                             -(ci[2] * g[0] + ci[4] * g[1] + ci[5] * g[2])};
+        double xc[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            xc[k] = fmin(fmax(x[k] + e[k], a.bound_lo), a.bound_hi);
+            const double st = xc[k] - x[k];
+            a.pts_out[3 * (size_t)p + k] = xc[k];
+            a.dp[3 * (size_t)p + k] = e[k];
+            a.gp[3 * (size_t)p + k] = g[k];
+            mcc += 0.5 * (lam[k] * e[k] * e[k] - g[k] * e[k]);
+            st2 += st * st;
+            x2 += x[k] * x[k];
+            gd += g[k] * e[k];
+            gm = fmax(gm, fabs(g[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { a.C[6 * (size_t)p + k] = c[k]; a.Cinv[6 * (size_t)p + k] = ci[k]; }
+        // the candidate's cost
+        for (uint32_t q = q0; q < q1; q++) {
+            PosePre pr;
+            pose_load(a.campre + kPoseStride * (size_t)a.q_cam[q], pr);
+            cost_c += residual_cost(pr, xc, a.uv[a.pt_obs[q]], P, a.huber_delta);
+        }
+    }
+    cost_x = wave_sum(cost_x); cost_c = wave_sum(cost_c); mcc = wave_sum(mcc); st2 = wave_sum(st2); x2 = wave_sum(x2);
+    gd = wave_sum(gd); gm = wave_max(gm);
+    const double badf = wave_max(bad ? 1.0 : 0.0);
+    if (threadIdx.x % kWave == 0) {
+        double* o = red + 8 * (threadIdx.x / kWave);
+        o[0] = cost_x; o[1] = cost_c; o[2] = mcc; o[3] = st2; o[4] = x2; o[5] = gd; o[6] = gm; o[7] = badf;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        double v = 0.0;
+        for (int w = 0; w < 16; w++) v = k >= 6 ? fmax(v, red[8 * w + k]) : v + red[8 * w + k];
+        if (k < 2) v *= 0.5;
+        fin[k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* sc = a.scal;
+        sc[SC_COST_X] = fin[0]; *a.cost_x_out = fin[0]; sc[SC_CAND_COST] = fin[1]; sc[SC_MCC_PTS] = fin[2]; sc[SC_STEP2_PTS] = fin[3]; sc[SC_X2_PTS] = fin[4];
+        sc[SC_GDOT_PTS] = fin[5]; sc[SC_GMAX_PTS] = fin[6]; sc[SC_STOP] = 0.0;
+        sc[SC_MCC_CAM] = 0.0; sc[SC_STEP2_CAM] = 0.0; sc[SC_X2_CAM] = 0.0; sc[SC_GDOT_CAM] = 0.0; sc[SC_GMAX_CAM] = 0.0;
+        sc[SC_LIN_ITERS] = 0.0; sc[SC_LIN_RESID] = 0.0; sc[SC_LIN_STATUS] = 0.0; sc[SC_SCHUR_STATUS] = fin[7];
+        const double mc = fin[2], cand = fin[1];
+        const bool ok = fin[7] == 0.0 && isfinite(mc) && isfinite(cand) && mc > 0.0 && cand <= a.x_cost + 1e-4 * fin[5];
+        sc[SC_GATE] = (a.gate_enabled && ok && (a.x_cost - cand) / mc > a.min_relative_decrease) ? 1.0 : 0.0;
+    }
+    publish_tail(pb);
+}
+
+void launch_points_step(hipStream_t s, const PointsStepArgs& a, const Proj& P, double* pub_src, int n_pub, int clear_first, int clear_n,
+                        double* host_dst, unsigned long long* host_seq, unsigned long long seq)
+{
+    hipLaunchKernelGGL(ba_points_step_kernel, dim3(1), dim3(1024), 0, s, a, P, Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
 }
 
 // ---- line search trial (TrustRegionMinimizer::DoLineSearch on bounded problems; run only when the full step fails the

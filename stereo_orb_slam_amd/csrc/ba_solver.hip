@@ -133,6 +133,7 @@ struct soslam_ba {
     bool linearized = false, scale_init = false;
     bool x_cost_known = false;          // x_cost is the cost at cams[cur], pts[cur] (accepted candidates: no sum over the tiles needed)
     bool campre_current = false;        // campre already holds the pose table of cams[cur] (set on acceptance, used once by linearize)
+    bool points_only_ready = false;     // structure-only path: both pose tables / camera buffers hold the constant poses, dc_full is zero
     int invalid_run = 0;
     std::vector<soslam_ba_iteration> log;
 
@@ -690,10 +691,16 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
 
 // ---- device pipeline ---------------------------------------------------------------------------------
 
-// residuals, Jacobians and the J^T J / J^T r blocks at the current state
-int linearize(soslam_ba* h)
+// Structure-only problems small enough for one workgroup take a whole LM iteration in one launch (ba_points_step): no
+// separate linearisation, no Schur complement, no camera system.  Not in multi-rank jobs (their sums cross ranks).
+bool points_only(const soslam_ba* h) { return h->n_free == 0 && h->n_pt > 0 && h->n_pt <= kPointsOnlyMax && !h->collective(); }
+
+// residuals, Jacobians and the J^T J / J^T r blocks at the current state.  in_lm_loop: called by the LM loop, which on
+// the structure-only path needs no linearisation of its own (every ba_points_step launch linearises at its x)
+int linearize(soslam_ba* h, bool in_lm_loop = false)
 {
     hipStream_t s = h->stream;
+    if (in_lm_loop && points_only(h)) { h->linearized = true; h->campre_current = false; return SOSLAM_OK; }
     {
         StageScope sc(h, SOSLAM_STAGE_LINEARIZE);
         // after an accepted step the candidate's pose table is already in place (swapped in by the LM loop)
@@ -811,6 +818,30 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
     unsigned long long published = 0;   // sequence number if the scalars were already handed to the host
     bool speculated = false;            // the linearisation at the candidate is enqueued behind the acceptance test
     const LmDiag lm = lm_diag(h, radius);
+    if (points_only(h)) {
+        // every camera constant: one launch per LM iteration (see PointsStepArgs)
+        if (!h->points_only_ready) {
+            launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);
+            launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre_c.p);
+            SOSLAM_HIP_CHECK(hipMemcpyAsync(h->cams[h->cur ^ 1].p, h->cams[h->cur].p, sizeof(double) * 6 * h->n_cam, hipMemcpyDeviceToDevice, s));
+            SOSLAM_CHECK(h->dc_full.zero(s));
+            h->points_only_ready = true;
+        }
+        StageScope sc(h, SOSLAM_STAGE_BACKSUB);
+        PointsStepArgs a{};
+        a.n_pt = h->n_pt; a.pt_start = h->pt_start.p; a.pt_obs = h->pt_obs.p; a.q_cam = h->q_cam.p; a.uv = h->uv.p;
+        a.campre = h->campre.p; a.pts = h->pts[h->cur].p; a.pts_out = h->pts[h->cur ^ 1].p; a.dp = h->dp.p;
+        a.C = h->C.p; a.gp = h->gp.p; a.sp = h->sp.p; a.Cinv = h->Cinv.p; a.lm = lm; a.huber_delta = h->opt.huber_delta;
+        a.bound_lo = h->opt.lower_bound; a.bound_hi = h->opt.upper_bound; a.init_scale = h->scale_init ? 0 : 1;
+        a.jacobi = h->opt.jacobi_scaling; a.scal = h->scalp(); a.cost_x_out = h->tail(); a.x_cost = h->x_cost;
+        a.min_relative_decrease = h->opt.min_relative_decrease; a.gate_enabled = 0;
+        (void)speculate; (void)stop_vote;
+        h->scale_init = true;
+        published = ++h->publish_seq;
+        launch_points_step(s, a, h->proj, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, h->host_raw, h->host_seq, published);
+        SOSLAM_HIP_CHECK(hipGetLastError());
+        return wait_host_seq(h, h->host_seq, published);
+    }
     {
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
         run_schur(h, lm);
@@ -1189,7 +1220,7 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
     h->stop_agreed = false;
     hipStream_t s = h->stream;
 
-    if (!h->linearized) SOSLAM_CHECK(linearize(h));
+    if (!h->linearized) SOSLAM_CHECK(linearize(h, true));
     // the solver / elimination status words start clean; every iteration's publication clears them again
     static_assert(SC_SCHUR_STATUS == SC_LIN_ITERS + 3, "status slots are contiguous");
     SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp() + SC_LIN_ITERS, 0, 4 * sizeof(double), s));
@@ -1208,7 +1239,7 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
             stop_vote = true;
         }
         if (h->stop_agreed) { h->stop_agreed = false; sum.termination = SOSLAM_TERM_TIME; break; }
-        if (!h->linearized) SOSLAM_CHECK(linearize(h));   // only after a speculative linearisation the host did not follow
+        if (!h->linearized) SOSLAM_CHECK(linearize(h, true));   // only after a speculative linearisation the host did not follow
         const double radius = h->radius;
         SOSLAM_CHECK(take_step(h, radius, true, stop_vote));
         StepScalars sc = read_scalars(h);
@@ -1294,7 +1325,7 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
                 h->campre_current = false;
                 h->linearized = true;
             } else {
-                SOSLAM_CHECK(linearize(h));
+                SOSLAM_CHECK(linearize(h, true));
             }
             double f = 1.0 - std::pow(2.0 * rel - 1.0, 3.0);
             if (f < 1.0 / 3.0) f = 1.0 / 3.0;
@@ -1475,6 +1506,8 @@ int soslam_ba_set_state(soslam_ba* h, const double* poses, const double* points)
     h->invalid_run = 0;
     h->linearized = false; h->x_cost_known = false;
     h->scale_init = false;
+    h->points_only_ready = false;
+    h->campre_current = false;
     h->have_state = true;
     return SOSLAM_OK;
 }
