@@ -91,7 +91,6 @@ struct soslam_ba {
     DevBuf<uint32_t> chunk_cam, free_cam;   // camera of each Schur window slot / of each free index
     DevBuf<double> long_wy;
     uint32_t n_long = 0, n_long_pairs = 0, n_short = 0;
-    std::vector<uint32_t> h_obs_cam, h_obs_pt;   // camera / internal point of each internal observation (debug read-back)
     DevBuf<uint32_t> row_ptr, ent_col, ent_blk, blk_row, blk_col;
     DevBuf<int32_t> cr_map;             // gather map of the cyclic-reduction assembly (crsolve.hip)
 
@@ -282,7 +281,15 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     // camera-major observation order: (camera, internal point)
     // (camera, internal point, caller index): stable counting sort by internal point, then by camera
     h->obs_int2user.resize(n_obs);
-    {
+    // The reference hands observations over frame by frame (bundle_adjuster.cpp:62-74), points in first-seen order: such an
+    // input is already in (camera, internal point, caller index) order.  One linear check instead of two counting sorts
+    // over the observations; the order itself, and every bit of the results, are those of the sort.
+    bool presorted = true;
+    for (uint32_t k = 1; k < n_obs && presorted; k++)
+        presorted = ocam[k] > ocam[k - 1] || (ocam[k] == ocam[k - 1] && h->pt_user2int[opt_[k]] >= h->pt_user2int[opt_[k - 1]]);
+    if (presorted) {
+        std::iota(h->obs_int2user.begin(), h->obs_int2user.end(), 0u);
+    } else {
         std::vector<uint32_t> tmp(n_obs), cnt(std::max(n_pt, n_cam) + 1);
         std::fill(cnt.begin(), cnt.begin() + n_pt + 1, 0u);
         for (uint32_t k = 0; k < n_obs; k++) cnt[h->pt_user2int[opt_[k]] + 1]++;
@@ -304,8 +311,6 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         cam_start[ocam[k] + 1]++;
     }
     for (uint32_t c = 0; c < n_cam; c++) cam_start[c + 1] += cam_start[c];
-    h->h_obs_cam = v_obs_cam;
-    h->h_obs_pt = v_obs_pt;
 
     SETUP_MARK("obs order");
     // tiles: <= kTileObs observations of one camera each
@@ -347,17 +352,19 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             if (use_bitmap) bits[(size_t)a * words_per_row + (b >> 6)] |= 1ull << (b & 63);
             else rows[a].push_back(b);
         };
-        std::vector<uint32_t> fc;
+        std::vector<uint32_t> fc, fc_prev;
         for (uint32_t f = 0; f < nf; f++) mark(f, f);
         for (uint32_t p = 0; p < n_pt; p++) {
             fc.clear();
             for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
-                const int32_t f = h->h_cam_free[v_obs_cam[pt_obs[q]]];
+                const int32_t f = h->h_cam_free[q_cam[q]];
                 if (f >= 0 && (fc.empty() || fc.back() != (uint32_t)f)) fc.push_back((uint32_t)f);
             }
             if (p < n_short) max_track = std::max<uint32_t>(max_track, (uint32_t)fc.size());
+            if (fc == fc_prev) continue;   // neighbouring points mostly share their camera set: its pairs are marked already
             for (size_t a = 0; a < fc.size(); a++)
                 for (size_t b = a + 1; b < fc.size(); b++) mark(fc[a], fc[b]);
+            fc_prev.swap(fc);
         }
         for (const auto& pr : h->covis) {
             if (pr.first >= n_cam || pr.second >= n_cam) {
@@ -460,10 +467,16 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                 bp = be;
             }
             ch.batch_end = (uint32_t)batches.size();
-            for (uint32_t q = pt_start[chunk_p0]; q < pt_start[p_end]; q++) {
-                const int32_t f = h->h_cam_free[v_obs_cam[pt_obs[q]]];
-                if (f < 0) continue;
-                q_slot[q] = (uint8_t)(std::lower_bound(local.begin(), local.end(), (uint32_t)f) - local.begin());
+            // window slot of every observation: a point's observations are camera-ascending and so is `local` - one
+            // merge walk per point instead of a binary search per observation
+            for (uint32_t pp = chunk_p0; pp < p_end; pp++) {
+                size_t sl = 0;
+                for (uint32_t q = pt_start[pp]; q < pt_start[pp + 1]; q++) {
+                    const int32_t f = h->h_cam_free[q_cam[q]];
+                    if (f < 0) continue;
+                    while (local[sl] < (uint32_t)f) sl++;
+                    q_slot[q] = (uint8_t)sl;
+                }
             }
             // slab layout of this chunk: [pair (a <= b < n_local)][36] then [camera a][6]; every pair whose block
             // exists in the pattern (it always does: the pattern is a superset) feeds that block's list
@@ -483,19 +496,22 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             chunk_p0 = p_end;
             local.clear();
         };
+        std::vector<uint32_t> fc_last;
         for (uint32_t p = 0; p < n_short; p++) {
             fc.clear();
             for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
-                const int32_t f = h->h_cam_free[v_obs_cam[pt_obs[q]]];
+                const int32_t f = h->h_cam_free[q_cam[q]];
                 if (f >= 0 && (fc.empty() || fc.back() != (uint32_t)f)) fc.push_back((uint32_t)f);
             }
+            if (p > chunk_p0 && p - chunk_p0 < chunk_pts_max && fc == fc_last) continue;   // same camera set as the point before: the window does not change
             merged.clear();
             std::set_union(local.begin(), local.end(), fc.begin(), fc.end(), std::back_inserter(merged));
             if ((int)merged.size() > K || p - chunk_p0 >= chunk_pts_max) {
                 close_chunk(p);
                 merged = fc;
             }
-            local = merged;
+            local.swap(merged);
+            fc_last = fc;
         }
         close_chunk(n_short);
     }
