@@ -100,6 +100,22 @@ int soslam_ba_get_state(soslam_ba* h, double* poses, double* points)
     return SOSLAM_OK;
 }
 
+/* the sharded entry points of the shim, for one rank (the oracle has no collective): enough to link the unchanged shim */
+int soslam_rccl_get_unique_id(void* id128) { memset(id128, 0, 128); return SOSLAM_OK; }
+int soslam_ba_init_rccl(soslam_ba* h, const void* id128, int32_t rank, int32_t world) { (void)h; (void)id128; return (rank == 0 && world == 1) ? SOSLAM_OK : SOSLAM_ERR_COMM; }
+int soslam_ba_set_covisibility(soslam_ba* h, uint64_t n, const uint32_t* a, const uint32_t* b) { (void)h; (void)n; (void)a; (void)b; return SOSLAM_OK; }
+void soslam_ba_shard_range(uint32_t n_pt, int32_t rank, int32_t world, uint32_t* begin, uint32_t* end)
+{
+    if (world < 1) world = 1;
+    if (begin) *begin = (uint32_t)(((uint64_t)rank * n_pt) / (uint64_t)world);
+    if (end) *end = (uint32_t)(((uint64_t)(rank + 1) * n_pt) / (uint64_t)world);
+}
+int soslam_ba_get_state_global(soslam_ba* h, double* poses, uint32_t n_pt_global, uint32_t shard_begin, double* points_global)
+{
+    if (shard_begin != 0 || n_pt_global != h->n_pt) return SOSLAM_ERR_INVALID_ARGUMENT;
+    return soslam_ba_get_state(h, poses, points_global);
+}
+
 int soslam_ba_solve(soslam_ba* h, soslam_ba_summary* summary)
 {
     oracle_ba_options o;

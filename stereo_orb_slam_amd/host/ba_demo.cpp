@@ -2,7 +2,7 @@
 // reference's Dump format, set the stereo projection, run BundleAdjuster::Optimize on a frame range (or the
 // per-frame + sliding-window schedule of slam.cpp:121-129), write the result as a Dump.
 //
-//   ba_demo <in_folder> <out_folder> [--start S] [--end E] [--schedule INTERVAL] [--iters N] [--quiet]
+//   ba_demo <in_folder> <out_folder> [--start S] [--end E] [--schedule INTERVAL] [--iters N] [--quiet] [--shard-one-rank]
 //           [--proj fx cx cy tx]   (rectified rig: P_l = K[I|0], P_r = K[I|t], P_r[3] = tx; default KITTI-00)
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +29,7 @@ int main(int argc, char** argv)
         return 2;
     }
     long start = 0, end = -1, schedule = 0, iters = -1;
-    bool quiet = false;
+    bool quiet = false, shard_one_rank = false;
     float fx = 718.856f, cx = 607.1928f, cy = 185.2157f, tx = -386.1448f;
     for (int i = 3; i < argc; i++) {
         if (!std::strcmp(argv[i], "--start") && i + 1 < argc) start = std::atol(argv[++i]);
@@ -37,6 +37,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--schedule") && i + 1 < argc) schedule = std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "--iters") && i + 1 < argc) iters = std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
+        else if (!std::strcmp(argv[i], "--shard-one-rank")) shard_one_rank = true;
         else if (!std::strcmp(argv[i], "--proj") && i + 4 < argc) { fx = (float)std::atof(argv[i + 1]); cx = (float)std::atof(argv[i + 2]); cy = (float)std::atof(argv[i + 3]); tx = (float)std::atof(argv[i + 4]); i += 4; }
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -48,6 +49,16 @@ int main(int argc, char** argv)
     InitializeStereoReprojectionError(fx, cx, cy, tx);
     BundleAdjuster ba(map.frames, map.points);
     if (quiet) ba.Options().verbose = 0;
+    if (shard_one_rank) {
+        // the multi-GPU path of the shim with the one rank a one-GPU box allows: unique id, communicator, sharding (the
+        // whole window is this rank's share), job-wide pattern, all-reduces, global read-back
+        unsigned char id[SOSLAM_RCCL_UNIQUE_ID_BYTES];
+        if (soslam_rccl_get_unique_id(id) != SOSLAM_OK) {
+            std::fprintf(stderr, "[FAIL]: no RCCL unique id: %s\n", soslam_last_error());
+            return 1;
+        }
+        ba.EnableSharding(0, 1, id);
+    }
     if (iters >= 0) ba.Options().max_iterations = (int32_t)iters;
     int rc = 0;
     if (schedule > 0) {

@@ -9,7 +9,9 @@
 //     points), then every window point is overwritten with its optimised position (:120-132).
 #include "bundle_adjuster.h"
 
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <unordered_map>
 
 #include "mat4f.h"
@@ -31,6 +33,13 @@ BundleAdjuster::BundleAdjuster(std::vector<Frame*>& cam_frames, std::vector<MapP
 }
 
 BundleAdjuster::~BundleAdjuster() { soslam_ba_destroy(m_handle); }
+
+void BundleAdjuster::EnableSharding(int rank, int world, const void* rccl_unique_id)
+{
+    m_rank = rank; m_world = world;
+    std::memcpy(m_rccl_id, rccl_unique_id, sizeof m_rccl_id);
+    m_comm_ready = false;
+}
 
 void BundleAdjuster::Optimize(unsigned int start_frame_id, unsigned int end_frame_id)
 {
@@ -76,12 +85,51 @@ void BundleAdjuster::Optimize(unsigned int start_frame_id, unsigned int end_fram
     // is only touched after every step has succeeded
     m_status = m_handle ? soslam_ba_set_options(m_handle, &m_options) : soslam_ba_create(&m_options, &m_handle);
     if (m_status == SOSLAM_OK) m_status = soslam_ba_set_projection(m_handle, ReprojectionError::p_l.data(), ReprojectionError::p_r.data());
-    if (m_status == SOSLAM_OK)
-        m_status = soslam_ba_set_problem(m_handle, n_cam, (uint32_t)point_ids.size(), (uint32_t)obs_cam.size(), obs_cam.data(),
-                                         obs_pt.data(), obs_uv.data(), fixed.data());
-    if (m_status == SOSLAM_OK) m_status = soslam_ba_set_state(m_handle, poses.data(), points.data());
-    if (m_status == SOSLAM_OK) m_status = soslam_ba_solve(m_handle, &m_summary);
-    if (m_status == SOSLAM_OK) m_status = soslam_ba_get_state(m_handle, poses.data(), points.data());
+    if (m_world > 0) {
+        // ---- sharded job: this rank's contiguous share of the window's points, every camera, the job-wide block pattern
+        if (m_status == SOSLAM_OK && !m_comm_ready) {
+            m_status = soslam_ba_init_rccl(m_handle, m_rccl_id, m_rank, m_world);   // collective over the ranks
+            m_comm_ready = m_status == SOSLAM_OK;
+        }
+        const uint32_t n_pt = (uint32_t)point_ids.size();
+        uint32_t pb = 0, pe = 0;
+        soslam_ba_shard_range(n_pt, m_rank, m_world, &pb, &pe);
+        std::vector<uint32_t> s_cam, s_pt;
+        std::vector<float> s_uv;
+        for (size_t k = 0; k < obs_cam.size(); k++) {
+            if (obs_pt[k] < pb || obs_pt[k] >= pe) continue;
+            s_cam.push_back(obs_cam[k]);
+            s_pt.push_back(obs_pt[k] - pb);
+            s_uv.insert(s_uv.end(), obs_uv.begin() + 4 * (std::ptrdiff_t)k, obs_uv.begin() + 4 * (std::ptrdiff_t)k + 4);
+        }
+        // camera pairs that share a point anywhere in the job: every rank lays the reduced system out alike
+        std::vector<std::vector<uint32_t>> cams_of(n_pt);
+        for (size_t k = 0; k < obs_cam.size(); k++) cams_of[obs_pt[k]].push_back(obs_cam[k]);
+        std::vector<uint64_t> keys;
+        for (const auto& cl : cams_of)
+            for (size_t a = 0; a < cl.size(); a++)
+                for (size_t b = a + 1; b < cl.size(); b++)
+                    if (cl[a] != cl[b]) keys.push_back(((uint64_t)std::min(cl[a], cl[b]) << 32) | std::max(cl[a], cl[b]));
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        std::vector<uint32_t> pa(keys.size()), pbv(keys.size());
+        for (size_t i = 0; i < keys.size(); i++) { pa[i] = (uint32_t)(keys[i] >> 32); pbv[i] = (uint32_t)(keys[i] & 0xFFFFFFFFu); }
+        if (m_status == SOSLAM_OK) m_status = soslam_ba_set_covisibility(m_handle, keys.size(), pa.data(), pbv.data());
+        if (m_status == SOSLAM_OK)
+            m_status = soslam_ba_set_problem(m_handle, n_cam, pe - pb, (uint32_t)s_cam.size(), s_cam.data(), s_pt.data(), s_uv.data(),
+                                             fixed.data());
+        if (m_status == SOSLAM_OK) m_status = soslam_ba_set_state(m_handle, poses.data(), points.data() + 3 * (size_t)pb);
+        if (m_status == SOSLAM_OK) m_status = soslam_ba_solve(m_handle, &m_summary);
+        // poses are replicated; the points of all ranks come together with one all-reduce
+        if (m_status == SOSLAM_OK) m_status = soslam_ba_get_state_global(m_handle, poses.data(), n_pt, pb, points.data());
+    } else {
+        if (m_status == SOSLAM_OK)
+            m_status = soslam_ba_set_problem(m_handle, n_cam, (uint32_t)point_ids.size(), (uint32_t)obs_cam.size(), obs_cam.data(),
+                                             obs_pt.data(), obs_uv.data(), fixed.data());
+        if (m_status == SOSLAM_OK) m_status = soslam_ba_set_state(m_handle, poses.data(), points.data());
+        if (m_status == SOSLAM_OK) m_status = soslam_ba_solve(m_handle, &m_summary);
+        if (m_status == SOSLAM_OK) m_status = soslam_ba_get_state(m_handle, poses.data(), points.data());
+    }
     if (m_status != SOSLAM_OK) {
         // the caller's map state is left untouched on failure (failure handling)
         std::fprintf(stderr, "[FAIL]: bundle adjustment failed: %s (%s)\n", soslam_status_string(m_status), soslam_last_error());

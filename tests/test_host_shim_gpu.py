@@ -51,6 +51,20 @@ def test_optimize_window_matches_oracle(demo, oracle_lib, tmp_path):
     assert c == pytest.approx(osum.final_cost, rel=1e-3)
 
 
+def test_sharded_shim_path_one_rank(demo, tmp_path):
+    """BundleAdjuster::EnableSharding - the shim's multi-GPU path (RCCL unique id, communicator on the handle, point shard
+    with the job-wide block pattern, all-reduces inside the LM iteration, global read-back of all ranks' points) - with
+    the one rank a one-GPU box allows.  A collective being attached only changes WHERE the sums are taken: the written-back
+    map must be the plain path's, byte for byte."""
+    from stereo_orb_slam_amd import dump_io, synth
+    p = synth.generate_ba(1)
+    dump_io.write_dump(str(tmp_path / "in"), p)
+    _run(demo, tmp_path / "in", tmp_path / "plain", "--iters", 10, "--quiet")
+    _run(demo, tmp_path / "in", tmp_path / "sharded", "--iters", 10, "--quiet", "--shard-one-rank")
+    for name in ("poses.txt", "points.txt"):
+        assert open(tmp_path / "plain" / name, "rb").read() == open(tmp_path / "sharded" / name, "rb").read(), name
+
+
 def test_half_open_range_and_untouched_frames(demo, tmp_path):
     """Optimize(2, 7) adjusts frames 2..6 only; frame 2 is the constant one; points never seen in the window
     keep their position (/root/reference/src/bundle_adjuster.cpp:62,113)."""
