@@ -209,10 +209,12 @@ void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double
 
 // cam_part[cam_update_blocks(n_cam)][5]: per-workgroup partials of the camera share of the step scalars (launch_step_sums
 // adds them into SC_MCC_CAM .. SC_GMAX_CAM)
-inline uint32_t cam_update_blocks(uint32_t n_cam) { return (n_cam * 6 + 255) / 256; }
+constexpr int kCamUpdateCams = 42;   // whole cameras per workgroup of ba_cam_update (252 of its 256 lanes)
+inline uint32_t cam_update_blocks(uint32_t n_cam) { return (n_cam + kCamUpdateCams - 1) / kCamUpdateCams; }
 void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams,
                        const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid, const double* campre,
-                       double* cams_out, double* dc_full, double* dcw /* [n_cam][6]: M dc_rot | dc_t */, double* cam_part);
+                       double* cams_out, double* dc_full, double* dcw /* [n_cam][6]: M dc_rot | dc_t */, double* cam_part,
+                       double* campre_c /* != NULL: the candidate's pose table, [n_cam][kPoseStride] */);
 
 void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
                     const double* ar, const double* campre, const double* dcw,

@@ -261,7 +261,9 @@ __device__ __forceinline__ void publish_tail(const Publish& pb)
         pb.host_dst[t] = pb.src[t];
         if (t >= pb.clear_first && t < pb.clear_first + pb.clear_n) pb.src[t] = 0.0;
     }
-    __threadfence_system();
+    // only the first wave has written anything (n <= 64): the other waves of a 1024-lane kernel skip the system-scope
+    // fence, whose cache write-back every wave would otherwise repeat
+    if (t < 64) __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __atomic_store_n(pb.host_seq, pb.seq, __ATOMIC_RELEASE);
 }
@@ -1013,7 +1015,8 @@ __global__ __launch_bounds__(256) void ba_cam_damp_kernel(uint32_t n_free, const
     S[36 * (size_t)diag_block[f] + a * 7] += lam;
 }
 
-// candidate cameras, full-length camera step, per-workgroup partials of the camera share of the step scalars
+// candidate cameras, full-length camera step, per-workgroup partials of the camera share of the step scalars, and the
+// candidate's pose table (what a ba_pose_prepare launch of its own did): a workgroup holds kCamUpdateCams whole cameras
 __global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, const int32_t* __restrict__ cam_free,
                                                             const double* __restrict__ cams,
                                                             const double* __restrict__ dc_free,
@@ -1021,13 +1024,15 @@ __global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, cons
                                                             const double* __restrict__ lin_resid,
                                                             const double* __restrict__ campre,
                                                             double* __restrict__ cams_out, double* __restrict__ dc_full,
-                                                            double* __restrict__ dcw, double* __restrict__ cam_part)
+                                                            double* __restrict__ dcw, double* __restrict__ cam_part,
+                                                            double* __restrict__ campre_c)
 {
     __shared__ double red[4 * 5];
+    __shared__ double xcand[kCamUpdateCams * 6];
     double mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_cam * 6) {
-        const uint32_t c = i / 6, a = i % 6;
+    const uint32_t c = blockIdx.x * kCamUpdateCams + threadIdx.x / 6, a = threadIdx.x % 6;
+    const uint32_t i = c * 6 + a;
+    if (threadIdx.x < kCamUpdateCams * 6 && c < n_cam) {
         const int32_t f = cam_free[c];
         const double x = cams[i];
         double d = 0.0;
@@ -1045,6 +1050,7 @@ __global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, cons
         const double e = xn - x;
         st2 += e * e;
         cams_out[i] = xn;
+        xcand[threadIdx.x] = xn;
         dc_full[i] = d;
         // what ba_backsub needs per camera: w = M dc_rot (the rotation part of J_c dc is A (w x v)) and dc_t; read from
         // the solver's output directly, so no lane depends on another lane's store
@@ -1070,6 +1076,11 @@ __global__ __launch_bounds__(256) void ba_cam_update_kernel(uint32_t n_cam, cons
         for (int w = 0; w < 4; w++) { a += red[w * 5]; b += red[w * 5 + 1]; c += red[w * 5 + 2]; d += red[w * 5 + 3]; e = fmax(e, red[w * 5 + 4]); }
         double* o = cam_part + 5 * (size_t)blockIdx.x;   // summed over the workgroups by ba_step_sums
         o[0] = a; o[1] = b; o[2] = c; o[3] = d; o[4] = e;
+    }
+    // the candidate's rotation block, one lane per camera of this workgroup (xcand was stored before the barrier above)
+    if (campre_c && threadIdx.x < kCamUpdateCams) {
+        const uint32_t cc = blockIdx.x * kCamUpdateCams + threadIdx.x;
+        if (cc < n_cam) pose_prepare(xcand + 6 * threadIdx.x, campre_c + kPoseStride * (size_t)cc);
     }
 }
 
@@ -1580,10 +1591,10 @@ void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double
 
 void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams,
                        const double* dc_free, const double* lc, const double* gc_red, const double* lin_resid, const double* campre,
-                       double* cams_out, double* dc_full, double* dcw, double* cam_part)
+                       double* cams_out, double* dc_full, double* dcw, double* cam_part, double* campre_c)
 {
     hipLaunchKernelGGL(ba_cam_update_kernel, dim3(cam_update_blocks(n_cam)), dim3(256), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red,
-                       lin_resid, campre, cams_out, dc_full, dcw, cam_part);
+                       lin_resid, campre, cams_out, dc_full, dcw, cam_part, campre_c);
 }
 
 void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,

@@ -924,7 +924,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
             }
         }
         launch_cam_update(s, h->n_cam, h->cam_free.p, h->cams[h->cur].p, h->dc_free.p, h->lc.p, h->gc_red(), resid, h->campre.p,
-                          h->cams[h->cur ^ 1].p, h->dc_full.p, h->dcw.p, h->cam_part.p);
+                          h->cams[h->cur ^ 1].p, h->dc_full.p, h->dcw.p, h->cam_part.p, h->campre_c.p);
     }
     {
         StageScope sc(h, SOSLAM_STAGE_BACKSUB);
@@ -934,9 +934,8 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
     }
     {
         StageScope sc(h, SOSLAM_STAGE_COST);
-        // the candidate gets its own pose table: campre stays at the linearisation point, the compact rows need it;
-        // an accepted step swaps the two tables instead of preparing the same poses again
-        launch_pose_prepare(s, h->n_cam, h->cams[h->cur ^ 1].p, h->campre_c.p);
+        // the candidate has its own pose table (written by ba_cam_update): campre stays at the linearisation point, the
+        // compact rows need it; an accepted step swaps the two tables instead of preparing the same poses again
         launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->proj,
                     h->opt.huber_delta, h->cost_part.p);
         // one launch for the back-substitution's step scalars and the candidate cost; on a single rank nothing follows
