@@ -201,8 +201,10 @@ __device__ __forceinline__ double residual_jacobian(const PosePre& pr, const dou
 // What ba_linearize needs per observation, without forming J_c or J_p: the corrected residual r, A (4x3: the
 // loss-corrected derivative of the image coordinates with respect to the camera-frame point) and D = d(R x)/dw (3x3).
 // Same arithmetic as residual_jacobian up to that point.  Returns rho(|r|^2).
-__device__ __forceinline__ double residual_ad(const PosePre& pr, const double* x, const float4 uv, const Proj& P, double delta,
-                                              double* __restrict__ r, double* __restrict__ Am, double* __restrict__ D)
+// r (loss-corrected), Am = the loss-corrected 4x3 derivative with respect to the camera-frame point, vv = the vector the
+// rotation derivative turns on (R x, or x on the first-order branch): J_c = [ A D | A ] with D = -[vv]x M.  Returns rho.
+__device__ __forceinline__ double residual_av(const PosePre& pr, const double* x, const float4 uv, const Proj& P, double delta,
+                                              double* __restrict__ r, double* __restrict__ Am, double* __restrict__ vv)
 {
     double yr[3], y[3];
 #pragma unroll
@@ -217,20 +219,28 @@ __device__ __forceinline__ double residual_ad(const PosePre& pr, const double* x
     double rho0, rho1;
     huber(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3], delta, rho0, rho1);
     const double sw = sqrt(rho1);
-    {
-        const double v0 = pr.small ? x[0] : yr[0], v1 = pr.small ? x[1] : yr[1], v2 = pr.small ? x[2] : yr[2];
-        const double* M = pr.M;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            D[0 * 3 + j] = -(v1 * M[2 * 3 + j] - v2 * M[1 * 3 + j]);
-            D[1 * 3 + j] = -(v2 * M[0 * 3 + j] - v0 * M[2 * 3 + j]);
-            D[2 * 3 + j] = -(v0 * M[1 * 3 + j] - v1 * M[0 * 3 + j]);
-        }
-    }
+    for (int i = 0; i < 3; i++) vv[i] = pr.small ? x[i] : yr[i];
 #pragma unroll
     for (int i = 0; i < 12; i++) Am[i] = A[i] * sw;
 #pragma unroll
     for (int i = 0; i < 4; i++) r[i] *= sw;
+    return rho0;
+}
+
+// the same with D = -[vv]x M written out (3x3 row-major)
+__device__ __forceinline__ double residual_ad(const PosePre& pr, const double* x, const float4 uv, const Proj& P, double delta,
+                                              double* __restrict__ r, double* __restrict__ Am, double* __restrict__ D)
+{
+    double vv[3];
+    const double rho0 = residual_av(pr, x, uv, P, delta, r, Am, vv);
+    const double* M = pr.M;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        D[0 * 3 + j] = -(vv[1] * M[2 * 3 + j] - vv[2] * M[1 * 3 + j]);
+        D[1 * 3 + j] = -(vv[2] * M[0 * 3 + j] - vv[0] * M[2 * 3 + j]);
+        D[2 * 3 + j] = -(vv[0] * M[1 * 3 + j] - vv[1] * M[0 * 3 + j]);
+    }
     return rho0;
 }
 

@@ -126,7 +126,8 @@ void launch_gate_publish(hipStream_t s, double* scal, double x_cost, double min_
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
-                       const double* tile_part, double* B /* [F][36] */, double* gc /* [F][6] */, const double* gate = nullptr);
+                       const double* tile_part /* sums without the camera constant M */, const double* campre, double* B /* [F][36] */,
+                       double* gc /* [F][6] */, const double* gate = nullptr);
 
 void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
                          const double* ar, const double* campre, double* C, double* gp, const double* gate = nullptr);

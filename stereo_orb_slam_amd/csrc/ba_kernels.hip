@@ -11,6 +11,7 @@
 // The kernels are HBM-bound streaming / gather work at a few flop/B; the one GEMM-shaped piece, the Schur window
 // product, runs on the f64 matrix cores.
 #include "ba_kernels.h"
+#include "reduce.h"
 
 namespace soslam {
 
@@ -18,18 +19,30 @@ namespace {
 
 constexpr int kWave = 64;
 
-__device__ __forceinline__ double wave_sum(double x)
+// The sums of N <= 32 values over the wave by a halving butterfly: at step k a lane keeps the half of its list that its bit
+// k selects and adds the partner's (lane ^ 2^k) copy of that half - 16 + 8 + 4 + 2 + 1 exchanges and one last add instead
+// of 6 N.  Every lane returns the sum of value number `index` (the low five lane bits reversed); fixed order of additions.
+template <int N>
+__device__ __forceinline__ double wave_sum_table(const double (&v)[N], const int lane, int& index)
 {
+    static_assert(N <= 32, "one value per lane of a half wave");
+    double w[32];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
-    return x;
-}
-
-__device__ __forceinline__ double wave_max(double x)
-{
+    for (int i = 0; i < 32; i++) w[i] = i < N ? v[i] : 0.0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_down(x, off, kWave));
-    return x;
+    for (int k = 0; k < 5; k++) {
+        const int half = 16 >> k;
+        const bool up = ((lane >> k) & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+            const double a = w[i], b = w[half + i];
+            const double send = up ? a : b, keep = up ? b : a;
+            w[i] = keep + __shfl_xor(send, 1 << k, kWave);
+        }
+    }
+    w[0] += __shfl_xor(w[0], 32, kWave);
+    index = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+    return w[0];
 }
 
 // per-camera rotation block (R, R*Jr, t, branch flag) - 24 f64 per camera, recomputed whenever poses change
@@ -102,8 +115,8 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
             xn[0] = pts[3 * pn]; xn[1] = pts[3 * pn + 1]; xn[2] = pts[3 * pn + 2];
         }
         if (act) {
-            double D[9];
-            v[27] += residual_ad(pr, x, m_all[j], P, delta, r, am, D);
+            double vv[3];
+            v[27] += residual_av(pr, x, m_all[j], P, delta, r, am, vv);
             // G = A^T A, h = A^T r: the compact row, and all the camera sums need
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -112,13 +125,25 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
                 hh[0] += a0 * r[i]; hh[1] += a1 * r[i]; hh[2] += a2 * r[i];
             }
             if (!fixed) {
-                // J_c = A [D | I]:  J_c^T J_c = [ D^T G D, D^T G ; G D, G ],  J_c^T r = [ D^T h ; h ]
+                // J_c = A [D | I], D = -E M with E = [vv]x and M the camera's constant:  D^T G D = M^T (E G E^T) M,
+                // D^T G = M^T (E G), D^T h = M^T (E h).  The tile sums hold the parts WITHOUT M - E G E^T, E G, G, E h, h,
+                // in the places of the 6x6 upper triangle and the gradient - and ba_cam_reduce applies M once per camera.
                 const double Gf[9] = {G[0], G[1], G[2], G[1], G[3], G[4], G[2], G[4], G[5]};
-                double K[9];   // D^T G
+                double Z[9];   // E G: column c = vv x G[:, c]
 #pragma unroll
-                for (int a = 0; a < 3; a++)
+                for (int c = 0; c < 3; c++) {
+                    Z[0 + c] = vv[1] * Gf[6 + c] - vv[2] * Gf[3 + c];
+                    Z[3 + c] = vv[2] * Gf[0 + c] - vv[0] * Gf[6 + c];
+                    Z[6 + c] = vv[0] * Gf[3 + c] - vv[1] * Gf[0 + c];
+                }
+                // E G E^T = -Z E: row a = vv x Z[a, :]
+                double Q[9];
 #pragma unroll
-                    for (int b = 0; b < 3; b++) K[a * 3 + b] = D[a] * Gf[b] + D[3 + a] * Gf[3 + b] + D[6 + a] * Gf[6 + b];
+                for (int a = 0; a < 3; a++) {
+                    Q[a * 3 + 0] = vv[1] * Z[a * 3 + 2] - vv[2] * Z[a * 3 + 1];
+                    Q[a * 3 + 1] = vv[2] * Z[a * 3 + 0] - vv[0] * Z[a * 3 + 2];
+                    Q[a * 3 + 2] = vv[0] * Z[a * 3 + 1] - vv[1] * Z[a * 3 + 0];
+                }
                 // upper triangle in the order (0,0) (0,1) .. (0,5) (1,1) .. (5,5)
                 int idx = 0;
 #pragma unroll
@@ -126,16 +151,16 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
 #pragma unroll
                     for (int b = a; b < 6; b++) {
                         double val;
-                        if (a < 3 && b < 3) val = K[a * 3] * D[b] + K[a * 3 + 1] * D[3 + b] + K[a * 3 + 2] * D[6 + b];
-                        else if (a < 3) val = K[a * 3 + (b - 3)];
+                        if (a < 3 && b < 3) val = Q[a * 3 + b];
+                        else if (a < 3) val = Z[a * 3 + (b - 3)];
                         else val = Gf[(a - 3) * 3 + (b - 3)];
                         v[idx++] += val;
                     }
+                v[21] += vv[1] * hh[2] - vv[2] * hh[1];
+                v[22] += vv[2] * hh[0] - vv[0] * hh[2];
+                v[23] += vv[0] * hh[1] - vv[1] * hh[0];
 #pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    v[21 + a] += D[a] * hh[0] + D[3 + a] * hh[1] + D[6 + a] * hh[2];
-                    v[24 + a] += hh[a];
-                }
+                for (int a = 0; a < 3; a++) v[24 + a] += hh[a];
             }
         }
         if (n_rows > 0) {
@@ -159,10 +184,10 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
             __builtin_amdgcn_wave_barrier();
         }
     }
-#pragma unroll
-    for (int i = 0; i < kTileVals; i++) {
-        const double sum = wave_sum(v[i]);
-        if (lane == 0) red[wave * kTileVals + i] = sum;
+    {
+        int idx;
+        const double sum = wave_sum_table(v, lane, idx);
+        if (lane < 32 && idx < kTileVals) red[wave * kTileVals + idx] = sum;
     }
     __syncthreads();
     if (tid < kTileVals) {
@@ -380,29 +405,58 @@ __global__ __launch_bounds__(64) void ba_gate_publish_kernel(double* __restrict_
     publish_tail(pb);
 }
 
-// K3  camera blocks from the tile partials: one 64-lane workgroup per camera, lanes 0..26 each own one
-// value and add the camera's tiles in order (bitwise reproducible).
+// K3  camera blocks from the tile partials: one 64-lane workgroup per camera, lanes 0..26 each own one value and add the
+// camera's tiles in order (bitwise reproducible).  The sums arrive without the camera's constant M (see ba_linearize):
+// B = T^T B~ T, g = T^T g~ with T = blockdiag(M, I) is applied here, once per camera instead of once per observation.
 __global__ __launch_bounds__(64) void ba_cam_reduce_kernel(const uint32_t* __restrict__ cam_tile_start,
                                                            const int32_t* __restrict__ cam_free,
                                                            const double* __restrict__ tile_part,
+                                                           const double* __restrict__ campre,
                                                            double* __restrict__ B, double* __restrict__ gc,
     const double* __restrict__ gate)
 {
+    __shared__ double bt[36], gt[6], Tm[36];
     if (gate && *gate == 0.0) return;   // speculative launch (see ba_step_sums_kernel): the step was not accepted
     const uint32_t cam = blockIdx.x;
     const int32_t f = cam_free[cam];
     const int v = threadIdx.x;
-    if (f < 0 || v >= 27) return;
-    double s = 0.0;
-    for (uint32_t t = cam_tile_start[cam]; t < cam_tile_start[cam + 1]; t++) s += tile_part[(size_t)t * kTileVals + v];
-    if (v < 21) {
-        int a = 0, rem = v;
-        while (rem >= 6 - a) { rem -= 6 - a; a++; }
-        const int b = a + rem;
-        B[36 * (size_t)f + a * 6 + b] = s;
-        B[36 * (size_t)f + b * 6 + a] = s;
-    } else {
-        gc[6 * (size_t)f + (v - 21)] = s;
+    if (f < 0) return;
+    if (v < 27) {
+        double s = 0.0;
+        for (uint32_t t = cam_tile_start[cam]; t < cam_tile_start[cam + 1]; t++) s += tile_part[(size_t)t * kTileVals + v];
+        if (v < 21) {
+            int a = 0, rem = v;
+            while (rem >= 6 - a) { rem -= 6 - a; a++; }
+            const int b = a + rem;
+            bt[a * 6 + b] = s;
+            bt[b * 6 + a] = s;
+        } else {
+            gt[v - 21] = s;
+        }
+    }
+    if (v < 36) {
+        const int i = v / 6, j = v % 6;
+        Tm[v] = (i < 3 && j < 3) ? campre[kPoseStride * (size_t)cam + 9 + i * 3 + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (v < 36) {
+        // B[a][b] = sum_ij T[i][a] B~[i][j] T[j][b], fixed order; the lower triangle mirrors the upper one
+        const int a0 = v / 6, b0 = v % 6, a = a0 < b0 ? a0 : b0, b = a0 < b0 ? b0 : a0;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double u = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) u += bt[i * 6 + j] * Tm[j * 6 + b];
+            s += Tm[i * 6 + a] * u;
+        }
+        B[36 * (size_t)f + v] = s;
+    } else if (v < 42) {
+        const int a = v - 36;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) s += Tm[i * 6 + a] * gt[i];
+        gc[6 * (size_t)f + a] = s;
     }
 }
 
@@ -1248,10 +1302,10 @@ void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out)
 }
 
 void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
-                       const double* tile_part, double* B, double* gc, const double* gate)
+                       const double* tile_part, const double* campre, double* B, double* gc, const double* gate)
 {
     if (!n_cam) return;
-    hipLaunchKernelGGL(ba_cam_reduce_kernel, dim3(n_cam), dim3(64), 0, s, cam_tile_start, cam_free, tile_part, B, gc, gate);
+    hipLaunchKernelGGL(ba_cam_reduce_kernel, dim3(n_cam), dim3(64), 0, s, cam_tile_start, cam_free, tile_part, campre, B, gc, gate);
 }
 
 void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,

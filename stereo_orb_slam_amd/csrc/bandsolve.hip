@@ -14,6 +14,7 @@
 #include "linsolve.h"
 
 #include "ba_kernels.h"
+#include "reduce.h"
 
 namespace soslam {
 
@@ -21,13 +22,6 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kFactorThreads = 320;
-
-__device__ __forceinline__ double wave_sum(double x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
-    return x;
-}
 
 __device__ __forceinline__ double block_sum(double v, double* red)
 {

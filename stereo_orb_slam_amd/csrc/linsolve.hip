@@ -5,6 +5,7 @@
 #include "linsolve.h"
 
 #include "ba_kernels.h"
+#include "reduce.h"
 
 namespace soslam {
 
@@ -12,13 +13,6 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kNB = 32;  // dense Cholesky panel width
-
-__device__ __forceinline__ double wave_sum(double x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
-    return x;
-}
 
 // sum over a 1024-lane workgroup, identical (fixed-order) result in every lane
 __device__ __forceinline__ double block_sum(double v, double* red)

@@ -11,6 +11,7 @@
 // agree bit for bit on alpha, beta and on convergence, and a converged solve turns the remaining launches of a
 // chunk into immediate returns.
 #include "linsolve.h"
+#include "reduce.h"
 
 #include <algorithm>
 #include <cmath>
@@ -36,13 +37,6 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ part, 
     double s = 0.0;
     for (uint32_t i = 0; i < n; i++) s += part[i];
     return s;
-}
-
-__device__ __forceinline__ double wave_sum(double x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    return x;
 }
 
 __device__ __forceinline__ double block_sum256(double v, double* red)

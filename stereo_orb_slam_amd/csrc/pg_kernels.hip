@@ -6,6 +6,7 @@
 // launch/latency-bound, not HBM-bound; one lane per edge or vertex, f64 atomics for the
 // block scatter (2.4 M adds per linearisation, far below the atomic rate).
 #include "pg_kernels.h"
+#include "reduce.h"
 
 namespace soslam {
 
@@ -106,13 +107,6 @@ __device__ __forceinline__ void huber_chi(double e2, double delta, double& rho0,
     const double dsqr = delta * delta;
     if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
     else { const double s = sqrt(e2); rho0 = 2.0 * s * delta - dsqr; rho1 = delta / s; }
-}
-
-__device__ __forceinline__ double wave_sum(double x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    return x;
 }
 
 // out = A^T (W B) for 6x6 row-major blocks
@@ -279,8 +273,7 @@ __global__ __launch_bounds__(1024) void pg_reduce_kernel(const double* __restric
     if (diag_block)
         for (uint32_t i = threadIdx.x; i < n_free * 6; i += 1024) m = fmax(m, fabs(H[36 * (size_t)diag_block[i / 6] + (i % 6) * 7]));
     s = wave_sum(s);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    m = wave_max(m);
     if (threadIdx.x % 64 == 0) { red[threadIdx.x / 64] = s; redm[threadIdx.x / 64] = m; }
     __syncthreads();
     if (threadIdx.x == 0) {
