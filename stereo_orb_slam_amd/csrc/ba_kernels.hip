@@ -22,6 +22,19 @@ constexpr int kWave = 64;
 // The sums of N <= 32 values over the wave by a halving butterfly: at step k a lane keeps the half of its list that its bit
 // k selects and adds the partner's (lane ^ 2^k) copy of that half - 16 + 8 + 4 + 2 + 1 exchanges and one last add instead
 // of 6 N.  Every lane returns the sum of value number `index` (the low five lane bits reversed); fixed order of additions.
+template <int N, int K>
+__device__ __forceinline__ void wave_sum_table_step(double (&w)[32], const int lane)
+{
+    constexpr int half = 16 >> K;
+    const bool up = ((lane >> K) & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < half; i++) {
+        const double a = w[i], b = w[half + i];
+        const double send = up ? a : b, keep = up ? b : a;
+        w[i] = keep + lane_xor_pow2<K>(send);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ double wave_sum_table(const double (&v)[N], const int lane, int& index)
 {
@@ -29,20 +42,14 @@ __device__ __forceinline__ double wave_sum_table(const double (&v)[N], const int
     double w[32];
 #pragma unroll
     for (int i = 0; i < 32; i++) w[i] = i < N ? v[i] : 0.0;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int half = 16 >> k;
-        const bool up = ((lane >> k) & 1) != 0;
-#pragma unroll
-        for (int i = 0; i < half; i++) {
-            const double a = w[i], b = w[half + i];
-            const double send = up ? a : b, keep = up ? b : a;
-            w[i] = keep + __shfl_xor(send, 1 << k, kWave);
-        }
-    }
-    w[0] += __shfl_xor(w[0], 32, kWave);
+    wave_sum_table_step<N, 0>(w, lane);
+    wave_sum_table_step<N, 1>(w, lane);
+    wave_sum_table_step<N, 2>(w, lane);
+    wave_sum_table_step<N, 3>(w, lane);
+    wave_sum_table_step<N, 4>(w, lane);
+    const F64Pair p = swap_halves32(w[0]);
     index = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
-    return w[0];
+    return p.a + p.b;
 }
 
 // per-camera rotation block (R, R*Jr, t, branch flag) - 24 f64 per camera, recomputed whenever poses change
@@ -498,12 +505,9 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n
             g2 += R[2] * w[6] + R[5] * w[7] + R[8] * w[8];
         }
     }
-#pragma unroll
-    for (int off = 1; off < kBacksubLanes; off <<= 1) {
-        c0 += __shfl_xor(c0, off, kWave); c1 += __shfl_xor(c1, off, kWave); c2 += __shfl_xor(c2, off, kWave);
-        c3 += __shfl_xor(c3, off, kWave); c4 += __shfl_xor(c4, off, kWave); c5 += __shfl_xor(c5, off, kWave);
-        g0 += __shfl_xor(g0, off, kWave); g1 += __shfl_xor(g1, off, kWave); g2 += __shfl_xor(g2, off, kWave);
-    }
+    static_assert(kBacksubLanes == 4, "quad_sum adds the four lanes of a point");
+    c0 = quad_sum(c0); c1 = quad_sum(c1); c2 = quad_sum(c2); c3 = quad_sum(c3); c4 = quad_sum(c4); c5 = quad_sum(c5);
+    g0 = quad_sum(g0); g1 = quad_sum(g1); g2 = quad_sum(g2);
     if (!live || sub != 0) return;
     double* Cp = C + 6 * (size_t)p;
     Cp[0] = c0; Cp[1] = c1; Cp[2] = c2; Cp[3] = c3; Cp[4] = c4; Cp[5] = c5;
@@ -1185,10 +1189,7 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
             t2 += R[2] * z0 + R[5] * z1 + R[8] * z2;
         }
     }
-#pragma unroll
-    for (int off = 1; off < kBacksubLanes; off <<= 1) {
-        t0 += __shfl_xor(t0, off, kWave); t1 += __shfl_xor(t1, off, kWave); t2 += __shfl_xor(t2, off, kWave);
-    }
+    t0 = quad_sum(t0); t1 = quad_sum(t1); t2 = quad_sum(t2);
     if (live && sub == 0) {
         const double g[3] = {gp[3 * (size_t)p], gp[3 * (size_t)p + 1], gp[3 * (size_t)p + 2]};
         t0 += g[0]; t1 += g[1]; t2 += g[2];

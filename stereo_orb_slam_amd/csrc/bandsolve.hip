@@ -486,8 +486,8 @@ __global__ __launch_bounds__(256) void pcg_band_matvec_kernel(const BsrView A, c
             }
         }
     }
-#pragma unroll
-    for (int off = 1; off < kMatvecLanes; off <<= 1) s += __shfl_xor(s, off, 64);
+    static_assert(kMatvecLanes == 4, "quad_sum adds the four lanes of a row");
+    s = quad_sum(s);
     double pq = 0.0;
     if (i < n && sub == 0) {
         q[i] = s;

@@ -41,6 +41,24 @@ __device__ __forceinline__ F64Pair swap_halves32(const double x)
     return F64Pair{__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1])};
 }
 
+// the value of lane ^ 2^K: DPP where a single control word does it (1, 2: quad permutes; 8: row rotation), the LDS crossbar otherwise
+template <int K>
+__device__ __forceinline__ double lane_xor_pow2(const double x)
+{
+    if constexpr (K == 0) return mov_dpp_f64<kDppXor1>(x);
+    else if constexpr (K == 1) return mov_dpp_f64<kDppXor2>(x);
+    else if constexpr (K == 3) return mov_dpp_f64<0x128>(x);   // row_ror:8
+    else return __shfl_xor(x, 1 << K, 64);
+}
+
+// the sum over each aligned group of four lanes (in all four): two quad permutes
+__device__ __forceinline__ double quad_sum(double x)
+{
+    x += mov_dpp_f64<kDppXor1>(x);
+    x += mov_dpp_f64<kDppXor2>(x);
+    return x;
+}
+
 __device__ __forceinline__ double wave_sum(double x)
 {
     x += mov_dpp_f64<kDppXor1>(x);
