@@ -54,6 +54,8 @@ struct SchurChunk {  // one workgroup of ba_schur
 struct SchurBatch {
     uint32_t q_begin, q_end;  // point-major observation positions
     uint32_t p_begin, p_end;  // internal point range
+    uint32_t full;            // 1: a whole batch of points, each observed by every camera of the window, none of them fixed -
+                              // the batch overwrites every element of the LDS image it reads (no zeroing needed)
 };
 // A point seen by more free cameras than the widest Schur window (32), or with more observations than a batch
 // holds, is eliminated by the long-track kernels: its W / Y blocks go to a scratch array and one 36-lane group per
@@ -138,8 +140,8 @@ void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacob
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
                   const uint32_t* chunk_slab, const uint32_t* chunk_cam /* [n_chunks][kmax] camera of each window slot */,
                   const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* ar, const double* campre,
-                  const double* pts, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv, double* slab,
-                  double* scal);
+                  const double* pts, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv,
+                  double* ptfac /* [n_pt][9] scratch: L^-T and L^-1 g of the damped point blocks */, double* slab, double* scal);
 
 // Multi-rank jobs: a rank whose point elimination failed (SC_SCHUR_STATUS) turns its share of the candidate cost
 // into +inf before the scalars are summed, so every rank sees a non-finite candidate and rejects the step alike.

@@ -505,9 +505,9 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n
             g2 += R[2] * w[6] + R[5] * w[7] + R[8] * w[8];
         }
     }
-    static_assert(kBacksubLanes == 4, "quad_sum adds the four lanes of a point");
-    c0 = quad_sum(c0); c1 = quad_sum(c1); c2 = quad_sum(c2); c3 = quad_sum(c3); c4 = quad_sum(c4); c5 = quad_sum(c5);
-    g0 = quad_sum(g0); g1 = quad_sum(g1); g2 = quad_sum(g2);
+    c0 = group_sum<kBacksubLanes>(c0); c1 = group_sum<kBacksubLanes>(c1); c2 = group_sum<kBacksubLanes>(c2);
+    c3 = group_sum<kBacksubLanes>(c3); c4 = group_sum<kBacksubLanes>(c4); c5 = group_sum<kBacksubLanes>(c5);
+    g0 = group_sum<kBacksubLanes>(g0); g1 = group_sum<kBacksubLanes>(g1); g2 = group_sum<kBacksubLanes>(g2);
     if (!live || sub != 0) return;
     double* Cp = C + 6 * (size_t)p;
     Cp[0] = c0; Cp[1] = c1; Cp[2] = c2; Cp[3] = c3; Cp[4] = c4; Cp[5] = c5;
@@ -554,7 +554,8 @@ constexpr int kRawPieces = kRawRow / 2;           // 16-byte pieces per row
 // lanes - their 78 accumulator tiles need the registers of eight waves.
 constexpr int schur_threads(int kmax) { return kmax <= 16 ? 256 : 512; }
 constexpr int kCamTab = 10;                       // per window camera: R (9), first-order-branch flag
-constexpr int kPointVals = 15;                    // per point: J_p^T J_p (6), Jacobi scale (3), J_p^T r (3), position (3)
+constexpr int kPointVals = 12;                    // per point and batch: M = L^-T (6), t = L^-1 J_p^T r (3), position (3)
+constexpr int kPtFac = 9;                         // per point in global memory: M (6), t (3) - written by the chunk's prologue
 
 typedef double schur_double4 __attribute__((ext_vector_type(4)));
 
@@ -572,8 +573,7 @@ struct SchurShape {
     static constexpr int NT = schur_threads(KMAX);         // lanes per workgroup
     static constexpr int TPW = (NUP + NT / 64 - 1) / (NT / 64);   // tiles per wave
     static constexpr size_t lds_bytes =
-        sizeof(double) * ((size_t)kBatchObs * kRawRow + (size_t)KB * LD + 2 * (PB * 6 + KB + PB * 3) + KMAX * kCamTab + PB * kPointVals) +
-        2 * kBatchObs;
+        sizeof(double) * ((size_t)kBatchObs * kRawRow + (size_t)KB * LD + 2 * (PB * 6 + KB + PB * 3) + KMAX * kCamTab) + 2 * kBatchObs;
     static_assert(LD >= ROWS && LD % 32 == 16, "image leading dimension");
 };
 
@@ -635,14 +635,50 @@ __device__ __forceinline__ void schur_mfma_dispatch(int n_act, const double* con
     }
 }
 
+// Full four-tile-row windows on four waves (nine or ten cameras - the reference's usual track length): the ten tiles are dealt
+// so that a wave's tiles share operand blocks, and each 16-column block of the image is read ONCE per k step and wave and
+// used in every product it appears in (an operand block is the same data whether it feeds A or B):
+//   wave 0: (0,0) (0,1) (0,2)   blocks 0 1 2        wave 2: (2,2) (2,3)   blocks 2 3
+//   wave 1: (1,1) (1,2) (1,3)   blocks 1 2 3        wave 3: (0,3) (3,3)   blocks 0 3
+// ten block reads per k step instead of twenty - the kernel is bound by LDS traffic (182 KB per batch and workgroup, half
+// of it operand reads), not by the matrix pipe.
+template <int KB, int LD>
+__device__ __forceinline__ void schur_mfma_shared4(const int wave, const double* __restrict__ x0p, const double* __restrict__ x1p,
+                                                   const double* __restrict__ x2p, schur_double4 (&acc)[3])
+{
+    if (wave < 2) {
+#pragma unroll
+        for (int k0 = 0; k0 < KB; k0 += 4) {
+            const double x0 = x0p[k0 * LD], x1 = x1p[k0 * LD], x2 = x2p[k0 * LD];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x2, acc[2], 0, 0, 0);
+        }
+    } else if (wave == 2) {
+#pragma unroll
+        for (int k0 = 0; k0 < KB; k0 += 4) {
+            const double x0 = x0p[k0 * LD], x1 = x1p[k0 * LD];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, acc[1], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int k0 = 0; k0 < KB; k0 += 4) {
+            const double x0 = x0p[k0 * LD], x1 = x1p[k0 * LD];
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc[1], 0, 0, 0);
+        }
+    }
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_schur_kernel(
     const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches, const uint32_t* __restrict__ chunk_slab,
     const uint32_t* __restrict__ chunk_cam, const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_pt,
     const uint8_t* __restrict__ q_slot, const double* __restrict__ ar, const double* __restrict__ campre,
     const double* __restrict__ pts, const double* __restrict__ C, const double* __restrict__ gp,
-    const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv, double* __restrict__ slab,
-    double* __restrict__ scal)
+    const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv, double* __restrict__ ptfac,
+    double* __restrict__ slab, double* __restrict__ scal)
 {
     using Sh = SchurShape<KMAX>;
     constexpr int NT = Sh::NT, PB = Sh::PB, LD = Sh::LD, KB = Sh::KB, NT1 = Sh::NT1, NUP = Sh::NUP, TPW = Sh::TPW;
@@ -657,8 +693,7 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
     double* const gl = cil + 2 * PB * 6;                  // [2][KB]    t = L^-1 J_p^T r of the batch's points, index 3 pl + c
     double* const xl = gl + 2 * KB;                       // [2][PB][3] the batch's points (linearisation point)
     double* const camtab = xl + 2 * PB * 3;               // [KMAX][10] R and branch flag of the window's cameras
-    double* const ptin = camtab + KMAX * kCamTab;         // [PB][15] the next batch's point data on its way to the point lanes
-    uint8_t* const pt_l = reinterpret_cast<uint8_t*>(ptin + PB * kPointVals);    // batch-local point of each staged observation
+    uint8_t* const pt_l = reinterpret_cast<uint8_t*>(camtab + KMAX * kCamTab);   // batch-local point of each staged observation
     uint8_t* const slot_l = pt_l + kBatchObs;                                    // its window slot (255: fixed camera)
 
     const SchurChunk ch = chunks[blockIdx.x];
@@ -667,11 +702,59 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
     const int K = (int)ch.n_local, rows_used = 6 * K;
     const int ptl = tid - (NT - 64);   // point lane of the last wave (negative elsewhere)
 
+    // The chunk's batch descriptors live in registers, lane l of every wave holding batch l: the three descriptors a loop
+    // iteration needs (this batch, the next one's rows, the one after's indices) are lane reads, not scalar loads with a
+    // wait for the scalar cache in front of each (about 300 cycles apiece, three times per batch).
+    const uint32_t n_batch = ch.batch_end - ch.batch_begin;
+    SchurBatch bd_mine = n_batch ? batches[ch.batch_begin + ((uint32_t)lane < n_batch ? (uint32_t)lane : n_batch - 1)] : SchurBatch{0, 0, 0, 0, 0};
+    auto batch_at = [&](uint32_t bi) __attribute__((always_inline)) -> SchurBatch {
+        const uint32_t r = bi - ch.batch_begin;   // wave-uniform
+        if (r >= 64) return batches[bi];
+        SchurBatch b;
+        b.q_begin = (uint32_t)__builtin_amdgcn_readlane((int)bd_mine.q_begin, (int)r);
+        b.q_end = (uint32_t)__builtin_amdgcn_readlane((int)bd_mine.q_end, (int)r);
+        b.p_begin = (uint32_t)__builtin_amdgcn_readlane((int)bd_mine.p_begin, (int)r);
+        b.p_end = (uint32_t)__builtin_amdgcn_readlane((int)bd_mine.p_end, (int)r);
+        b.full = (uint32_t)__builtin_amdgcn_readlane((int)bd_mine.full, (int)r);
+        return b;
+    };
+
     // the window cameras' rotations, once per chunk (read by the W/Y lanes after the first barrier of the loop)
     for (int e = tid; e < K * kCamTab; e += NT) {
         const int slot = e / kCamTab, i = e - slot * kCamTab;
         camtab[e] = campre[kPoseStride * (size_t)chunk_cam[(size_t)blockIdx.x * KMAX + slot] + (i < 9 ? i : 21)];
     }
+
+    // The chunk's points, all at once, one lane each: Cholesky factor of the damped 3x3 block, M = L^-T, t = L^-1 g = M^T g and
+    // C^-1 = M M^T.  A long dependent f64 chain (three square roots, the divisions behind them) - taken once per chunk with
+    // every lane busy, not once per batch on twelve lanes of one wave with the other waves waiting at the barrier for it
+    // (measured: 2 550 of the 9 000 cycles of a batch).  M and t go to global memory (72 B per point, read back a batch
+    // ahead by the point lanes), C^-1 is an output anyway (ba_backsub).
+    for (uint32_t idx = tid; idx < (ch.batch_end - ch.batch_begin) * (uint32_t)PB; idx += NT) {
+        const SchurBatch bt = batches[ch.batch_begin + idx / PB];
+        const uint32_t pl = idx % PB;
+        if (pl >= bt.p_end - bt.p_begin) continue;
+        const size_t p = (size_t)bt.p_begin + pl;
+        double c[6], mt[6], ci[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) c[i] = C[6 * p + i];
+        const double g0 = gp[3 * p], g1 = gp[3 * p + 1], g2 = gp[3 * p + 2];
+        const double m[6] = {c[0] + point_lambda(c[0], sp[3 * p], lm), c[1], c[2], c[3] + point_lambda(c[3], sp[3 * p + 1], lm), c[4],
+                             c[5] + point_lambda(c[5], sp[3 * p + 2], lm)};
+        if (!sym3_chol_inverse(m, mt, ci)) scal[SC_SCHUR_STATUS] = 1.0;
+        double* f = ptfac + kPtFac * p;
+        double* o = Cinv + 6 * p;
+#pragma unroll
+        for (int i = 0; i < 6; i++) { f[i] = mt[i]; o[i] = ci[i]; }
+        f[6] = mt[0] * g0;
+        f[7] = mt[1] * g0 + mt[3] * g1;
+        f[8] = mt[2] * g0 + mt[4] * g1 + mt[5] * g2;
+    }
+    // the point lanes of this workgroup read M and t back: same CU, same L1 - workgroup scope is all the ordering needed (an
+    // agent-scope fence here writes the whole L2 back, once per workgroup: measured 75 -> 150 us)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     // this wave's tiles of the upper triangle of the rows the chunk USES (a window of 11 cameras covers 5 of the 6 tile
     // rows a 16-camera window has): the used tiles u = wave, wave + NT/64, .. are dealt round the waves, so the matrix
@@ -690,6 +773,21 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
         }
         acc[j] = schur_double4{0.0, 0.0, 0.0, 0.0};
     }
+    // the operand-sharing deal of full four-row windows (see schur_mfma_shared4)
+    const bool shared4 = NT1 == 4 && NT == 256 && TPW == 3 && nt1_used == 4;
+    const double* xp[3] = {Ui, Ui, Ui};
+    if constexpr (TPW == 3) {
+        if (shared4) {
+            const int bi0 = wave == 3 ? 0 : wave;                       // the wave's blocks
+            const int bi1 = wave == 3 ? 3 : wave + 1, bi2 = wave + 2;   // (bi2 only on waves 0 and 1)
+            t_i0[0] = (wave == 3 ? 0 : wave) * 16; t_j0[0] = (wave == 3 ? 3 : wave) * 16;
+            t_i0[1] = (wave == 3 ? 3 : wave) * 16; t_j0[1] = (wave == 3 ? 3 : wave + 1) * 16;
+            t_i0[2] = wave < 2 ? wave * 16 : -1;   t_j0[2] = wave < 2 ? (wave + 2) * 16 : 0;
+            xp[0] = Ui + (lane / 16) * LD + bi0 * 16 + lane % 16;
+            xp[1] = Ui + (lane / 16) * LD + bi1 * 16 + lane % 16;
+            xp[2] = Ui + (lane / 16) * LD + (wave < 2 ? bi2 : 0) * 16 + lane % 16;
+        }
+    }
     // operand bases of the wave's tiles in the image (fixed for the chunk) and the number of tiles it owns
     const double* pa[TPW];
     const double* pb[TPW];
@@ -701,8 +799,16 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
         pb[j] = Ui + (lane / 16) * LD + t_j0[j] + lane % 16;
         n_act += t_i0[j] >= 0 ? 1 : 0;
     }
-    constexpr int kRhsGroups = 2;   // kRhsGroups * 6 KMAX <= NT lanes share the rhs product
-    double racc = 0.0;   // partial rhs of row tid % rows_used
+    // The rhs product U~ t belongs to one lane per window row, in the waves just below the point wave: those own the fewest
+    // tiles (the tiles are dealt from wave 0 up), so the product fills their idle time instead of lengthening the waves
+    // every barrier waits for.
+    constexpr int kRhsFirst = NT - 64 - ((Sh::ROWS + 63) / 64) * 64;
+    static_assert(kRhsFirst >= 0, "room for one rhs lane per window row below the point wave");
+    const int rrow = tid - kRhsFirst;   // this lane's row of the rhs (outside [0, rows_used): none)
+    double racc = 0.0;
+    // ... unless the window leaves a spare column in its last tile column (6 K is not a multiple of 16: every K but 8, 16,
+    // 24, 32): then t sits in image column 6 K, and the tiles of that column deliver U~ t in their column 6 K for nothing
+    const bool rhs_in_tiles = rows_used % 16 != 0;
 
     // Prefetch registers, one batch ahead: this lane's 16-byte pieces of the G part of the batch's compact rows; its
     // observation's point id and window slot; and - one lane per point - the point's J_p^T J_p, Jacobi scale, J_p^T r
@@ -730,13 +836,13 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
     auto p_part = [&](int s) __attribute__((always_inline)) { return p_pack[s] >> 16; };
     const char* const ar_b = reinterpret_cast<const char*>(ar);
     auto fetch_index = [&](uint32_t bi) __attribute__((always_inline)) {
-        const SchurBatch bt = batches[bi];
+        const SchurBatch bt = batch_at(bi);
         const int nq = (int)(bt.q_end - bt.q_begin);
 #pragma unroll
         for (int s = 0; s < PPT; s++) pre_row[s] = p_obs(s) < nq ? pt_obs[bt.q_begin + p_obs(s)] : 0u;
     };
     auto fetch = [&](uint32_t bi) __attribute__((always_inline)) {   // rows of batch bi through the indices fetch_index(bi) loaded earlier
-        const SchurBatch bt = batches[bi];
+        const SchurBatch bt = batch_at(bi);
         const int nq = (int)(bt.q_end - bt.q_begin), np = (int)(bt.p_end - bt.p_begin);
 #pragma unroll
         for (int s = 0; s < PPT; s++) {
@@ -752,55 +858,24 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
                 const int idx = ptl * kPtPerLane + u, pl = idx / kPointVals, v = idx - pl * kPointVals;
                 const size_t p = (size_t)bt.p_begin + pl;
                 double val = 0.0;
-                if (pl < np) val = v < 6 ? C[6 * p + v] : v < 9 ? sp[3 * p + (v - 6)] : v < 12 ? gp[3 * p + (v - 9)] : pts[3 * p + (v - 12)];
+                if (pl < np) val = v < kPtFac ? ptfac[kPtFac * p + v] : pts[3 * p + (v - kPtFac)];
                 pre_pv[u] = val;
             }
         }
     };
-    // One lane per point of a batch (the last wave): Cholesky factor of the damped 3x3 block, its inverse transpose
-    // M = L^-T, t = L^-1 g and C^-1 = M M^T in registers, for the batch AFTER the one being multiplied - a long dependent
-    // f64 chain on a few lanes that would otherwise stall every wave at a barrier.  Results go to the parity buffers
-    // of that batch.
+    // The point lanes (the last wave) hand the batch AFTER the one being multiplied its M, t and positions: plain copies into
+    // the parity buffers of that batch; lanes past the batch's points carry zeros (the k padding of the products).
     auto point_phase = [&](uint32_t bi) __attribute__((always_inline)) {
         if (ptl < 0) return;
-        // the wave's own exchange: written and read by the same wave, in program order
-#pragma unroll
-        for (int u = 0; u < kPtPerLane; u++) {
-            const int idx = ptl * kPtPerLane + u;
-            if (idx < PB * kPointVals) ptin[idx] = pre_pv[u];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-        if (ptl >= PB) return;
-        double pre_c[6], pre_s[3], pre_g[3], pre_p[3];
-#pragma unroll
-        for (int i = 0; i < 6; i++) pre_c[i] = ptin[ptl * kPointVals + i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            pre_s[i] = ptin[ptl * kPointVals + 6 + i]; pre_g[i] = ptin[ptl * kPointVals + 9 + i]; pre_p[i] = ptin[ptl * kPointVals + 12 + i];
-        }
-        const SchurBatch bt = batches[bi];
-        const int np = (int)(bt.p_end - bt.p_begin);
         double* cl = cil + (bi & 1) * (PB * 6);
         double* g = gl + (bi & 1) * KB;
         double* xp = xl + (bi & 1) * (PB * 3);
-        if (ptl < np) {
-            double mt[6], ci[6];
-            const double m[6] = {pre_c[0] + point_lambda(pre_c[0], pre_s[0], lm), pre_c[1], pre_c[2],
-                                 pre_c[3] + point_lambda(pre_c[3], pre_s[1], lm), pre_c[4], pre_c[5] + point_lambda(pre_c[5], pre_s[2], lm)};
-            if (!sym3_chol_inverse(m, mt, ci)) scal[SC_SCHUR_STATUS] = 1.0;
-            double* o = Cinv + 6 * ((size_t)bt.p_begin + ptl);
 #pragma unroll
-            for (int i = 0; i < 6; i++) { cl[ptl * 6 + i] = mt[i]; o[i] = ci[i]; }
-            // t = L^-1 g = M^T g
-            g[ptl * 3] = mt[0] * pre_g[0];
-            g[ptl * 3 + 1] = mt[1] * pre_g[0] + mt[3] * pre_g[1];
-            g[ptl * 3 + 2] = mt[2] * pre_g[0] + mt[4] * pre_g[1] + mt[5] * pre_g[2];
-#pragma unroll
-            for (int i = 0; i < 3; i++) xp[ptl * 3 + i] = pre_p[i];
-        } else {
-            g[ptl * 3] = 0.0; g[ptl * 3 + 1] = 0.0; g[ptl * 3 + 2] = 0.0;   // k padding of the rhs product
+        for (int u = 0; u < kPtPerLane; u++) {
+            const int idx = ptl * kPtPerLane + u, pl = idx / kPointVals, v = idx - pl * kPointVals;
+            if (idx >= PB * kPointVals) continue;
+            double* dst = v < 6 ? cl + pl * 6 + v : v < kPtFac ? g + pl * 3 + (v - 6) : xp + pl * 3 + (v - kPtFac);
+            *dst = pre_pv[u];
         }
     };
     if (ch.batch_begin < ch.batch_end) {
@@ -811,9 +886,8 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
     }
 
     for (uint32_t bi = ch.batch_begin; bi < ch.batch_end; bi++) {
-        const SchurBatch bt = batches[bi];
-        const int nq = (int)(bt.q_end - bt.q_begin), np = (int)(bt.p_end - bt.p_begin);
-        const int kb_used = (3 * np + 3) & ~3;
+        const SchurBatch bt = batch_at(bi);
+        const int nq = (int)(bt.q_end - bt.q_begin);
         lds_barrier();   // previous batch's products are done with the LDS images
 #pragma unroll
         for (int s = 0; s < PPT; s++)
@@ -825,8 +899,11 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
             fetch(bi + 1);
             if (bi + 2 < ch.batch_end) fetch_index(bi + 2);
         }
-        // zero the image (contiguous, 16-byte stores); absent cameras and the k padding stay zero
-        for (int e = tid; e < KB * LD / 2; e += NT) reinterpret_cast<double2*>(Ui)[e] = make_double2(0.0, 0.0);
+        // zero the image (contiguous, 16-byte stores); absent cameras and the k padding stay zero.  Not needed when the batch
+        // overwrites every element the products read (bt.full, set by the host): what is left over in the padding columns
+        // then only reaches accumulator columns that are never stored.
+        if (!bt.full)
+            for (int e = tid; e < KB * LD / 2; e += NT) reinterpret_cast<double2*>(Ui)[e] = make_double2(0.0, 0.0);
         if (tid < nq) { pt_l[tid] = (uint8_t)(my_pt - bt.p_begin); slot_l[tid] = my_slot; }
         const double* const cil_b = cil + (bi & 1) * (PB * 6);
         const double* const gl_b = gl + (bi & 1) * KB;
@@ -861,22 +938,32 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
                 }
             }
         }
+        if (rhs_in_tiles && tid < KB) Ui[tid * LD + rows_used] = gl_b[tid];
         lds_barrier();
         // window += Ui^T Ui over the batch's columns: lane l feeds A[i = l%16][k = l/16] and B[k = l/16][j = l%16], both
         // from the one image.  Straight-line code: the wave's n_act tiles (wave-uniform) pick one fully unrolled body, all
         // KB / 4 steps are taken (the k padding of a short batch is zero), every operand read is base + immediate offset
-        schur_mfma_dispatch<TPW, KB, LD>(n_act, pa, pb, acc);
-        // rhs part U~ t: lane group g = tid / rows_used takes the columns k = g (mod kRhsGroups); combined at the end
-        if (tid < kRhsGroups * rows_used) {
-            const int grp = tid / rows_used, rrow = tid - grp * rows_used;
+        if constexpr (TPW == 3) {
+            if (shared4) schur_mfma_shared4<KB, LD>(wave, xp[0], xp[1], xp[2], acc);
+            else schur_mfma_dispatch<TPW, KB, LD>(n_act, pa, pb, acc);
+        } else {
+            schur_mfma_dispatch<TPW, KB, LD>(n_act, pa, pb, acc);
+        }
+        // rhs part U~ t: all KB columns, straight-line (the k padding of a short batch is zero in both factors), every operand
+        // requested before the first product
+        if (!rhs_in_tiles && rrow >= 0 && rrow < rows_used) {
             const double* y = Ui + rrow;
+            constexpr int kStep = 12;   // operands in flight: 24 doubles (all KB at once would spill)
+            static_assert(KB % kStep == 0, "whole steps");
             double s0 = 0.0, s1 = 0.0;
-            int k = grp;
-            for (; k + kRhsGroups < kb_used; k += 2 * kRhsGroups) {
-                s0 += y[k * LD] * gl_b[k];
-                s1 += y[(k + kRhsGroups) * LD] * gl_b[k + kRhsGroups];
+#pragma unroll
+            for (int k0 = 0; k0 < KB; k0 += kStep) {
+                double yv[kStep], tv[kStep];
+#pragma unroll
+                for (int k = 0; k < kStep; k++) { yv[k] = y[(k0 + k) * LD]; tv[k] = gl_b[k0 + k]; }
+#pragma unroll
+                for (int k = 0; k < kStep; k += 2) { s0 += yv[k] * tv[k]; s1 += yv[k + 1] * tv[k + 1]; }
             }
-            if (k < kb_used) s0 += y[k * LD] * gl_b[k];
             racc += s0 + s1;
         }
         if (bi + 1 < ch.batch_end) point_phase(bi + 1);   // its inputs were requested at the top of this iteration
@@ -893,6 +980,7 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = t_i0[j] + 4 * r + lane / 16, col = t_j0[j] + lane % 16;
+            if (rhs_in_tiles && col == rows_used && row < rows_used) out[n_pair * 36 + row] = acc[j][r];
             if (row >= rows_used || col >= rows_used) continue;
             const int a = row / 6, rr = row - 6 * a, b = col / 6, cc = col - 6 * b;
             if (a > b) continue;
@@ -907,16 +995,7 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
             }
         }
     }
-    // rhs: the lane groups' partial sums are added in a fixed order through the (now idle) image memory
-    lds_barrier();
-    if (tid < kRhsGroups * rows_used) Ui[tid] = racc;
-    lds_barrier();
-    if (tid < rows_used) {
-        double s = Ui[tid];
-#pragma unroll
-        for (int g = 1; g < kRhsGroups; g++) s += Ui[g * rows_used + tid];
-        out[n_pair * 36 + tid] = s;
-    }
+    if (!rhs_in_tiles && rrow >= 0 && rrow < rows_used) out[n_pair * 36 + rrow] = racc;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1189,7 +1268,7 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
             t2 += R[2] * z0 + R[5] * z1 + R[8] * z2;
         }
     }
-    t0 = quad_sum(t0); t1 = quad_sum(t1); t2 = quad_sum(t2);
+    t0 = group_sum<kBacksubLanes>(t0); t1 = group_sum<kBacksubLanes>(t1); t2 = group_sum<kBacksubLanes>(t2);
     if (live && sub == 0) {
         const double g[3] = {gp[3 * (size_t)p], gp[3 * (size_t)p + 1], gp[3 * (size_t)p + 2]};
         t0 += g[0]; t1 += g[1]; t2 += g[2];
@@ -1327,7 +1406,7 @@ void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacob
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
                   const uint32_t* chunk_slab, const uint32_t* chunk_cam, const uint32_t* pt_obs, const uint32_t* q_pt,
                   const uint8_t* q_slot, const double* ar, const double* campre, const double* pts, const double* C, const double* gp,
-                  const double* sp, LmDiag lm, double* Cinv, double* slab, double* scal)
+                  const double* sp, LmDiag lm, double* Cinv, double* ptfac, double* slab, double* scal)
 {
     if (!n_chunks) return;
     if (kmax <= 10) {
@@ -1336,17 +1415,17 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
         constexpr size_t lds = SchurShape<10>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ba_schur_kernel<10>), dim3(n_chunks), dim3(schur_threads(10)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
-                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
+                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
     } else if (kmax <= 16) {
         constexpr size_t lds = SchurShape<16>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ba_schur_kernel<16>), dim3(n_chunks), dim3(schur_threads(16)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
-                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
+                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
     } else {
         constexpr size_t lds = SchurShape<32>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(schur_threads(32)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
-                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, slab, scal);
+                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
     }
 }
 

@@ -98,7 +98,7 @@ struct soslam_ba {
     DevBuf<double> cams[2], pts[2];
     int cur = 0;
     DevBuf<double> cam_part;            // [cam_update_blocks][5] partials of the camera share of the step scalars
-    DevBuf<double> campre, campre_c, ar, dcw, tile_part, cost_part, C, gp, sp, Cinv, B, gc, sc, lc, dc_free, dc_full, dp, part;
+    DevBuf<double> campre, campre_c, ar, dcw, tile_part, cost_part, C, gp, sp, Cinv, ptfac, B, gc, sc, lc, dc_free, dc_full, dp, part;
     DevBuf<double> lin_resid, lin_work, dense, band, bandT, band_dinv, cr_ws;
     DevBuf<double> reduce_own;          // library-owned reduce buffer
     double* reduce = nullptr;           // [S blocks | rhs | diagB | gc_red | tail(4)] [scalars(SC_COUNT)]
@@ -472,7 +472,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                     be++;
                 }
                 if (be == bp) be = bp + 1;  // single point wider than a batch cannot happen (track <= 32 + fixed)
-                batches.push_back(SchurBatch{pt_start[bp], pt_start[be], bp, be});
+                batches.push_back(SchurBatch{pt_start[bp], pt_start[be], bp, be, 0u});
                 bp = be;
             }
             ch.batch_end = (uint32_t)batches.size();
@@ -486,6 +486,13 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                     while (local[sl] < (uint32_t)f) sl++;
                     q_slot[q] = (uint8_t)sl;
                 }
+            }
+            for (uint32_t b = ch.batch_begin; b < ch.batch_end; b++) {
+                SchurBatch& bt = batches[b];
+                bool full = bt.p_end - bt.p_begin == (uint32_t)schur_batch_points(K) &&
+                            bt.q_end - bt.q_begin == (bt.p_end - bt.p_begin) * (uint32_t)local.size();
+                for (uint32_t q = bt.q_begin; full && q < bt.q_end; q++) full = q_slot[q] != 255;
+                bt.full = full ? 1u : 0u;
             }
             // slab layout of this chunk: [pair (a <= b < n_local)][36] then [camera a][6]; every pair whose block
             // exists in the pattern (it always does: the pattern is a superset) feeds that block's list
@@ -657,6 +664,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->gp.alloc((size_t)n_pt * 3));
     SOSLAM_CHECK(h->sp.alloc((size_t)n_pt * 3));
     SOSLAM_CHECK(h->Cinv.alloc((size_t)n_pt * 6));
+    SOSLAM_CHECK(h->ptfac.alloc((size_t)n_pt * 9));
     SOSLAM_CHECK(h->B.alloc((size_t)nf * 36));
     SOSLAM_CHECK(h->gc.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->sc.alloc((size_t)nf * 6));
@@ -828,7 +836,7 @@ void run_schur(soslam_ba* h, const LmDiag& lm)
 {
     hipStream_t s = h->stream;
     launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pt_obs.p, h->q_pt.p,
-                 h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p, h->scalp());
+                 h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p, h->scalp());
     launch_schur_long(s, h->n_long, h->long_pts.p, h->lo_row.p, h->lo_cam.p, h->lo_cam_off.p, h->n_long_pairs, h->pair_a.p, h->pair_b.p,
                       h->pair_off.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->long_wy.p,
                       h->slab.p, h->scalp());
@@ -1714,7 +1722,7 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
             break;
         case SOSLAM_KERNEL_SCHUR:
             launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pt_obs.p, h->q_pt.p,
-                         h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->slab.p,
+                         h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p,
                          h->scalp());
             break;
         case SOSLAM_KERNEL_BACKSUB:

@@ -59,6 +59,17 @@ __device__ __forceinline__ double quad_sum(double x)
     return x;
 }
 
+// the sum over each aligned group of L = 4, 8 or 16 lanes (in all of them)
+template <int L>
+__device__ __forceinline__ double group_sum(double x)
+{
+    static_assert(L == 4 || L == 8 || L == 16, "group sizes a DPP row covers");
+    x = quad_sum(x);
+    if constexpr (L >= 8) x += mov_dpp_f64<kDppHalfMirror>(x);
+    if constexpr (L >= 16) x += mov_dpp_f64<kDppMirror>(x);
+    return x;
+}
+
 __device__ __forceinline__ double wave_sum(double x)
 {
     x += mov_dpp_f64<kDppXor1>(x);
