@@ -137,11 +137,13 @@ void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start,
 void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacobi, double* sp);
 
 // chunk windows into per-chunk slabs (chunk_slab[c] = offset of chunk c, layout [pair][36] then [camera][6])
+constexpr int kS10PairsPerBatch = 120;   // (point, window slot) pairs of a batch of the ten-camera kernel: 12 points x 10 slots
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
                   const uint32_t* chunk_slab, const uint32_t* chunk_cam /* [n_chunks][kmax] camera of each window slot */,
+                  const uint32_t* pair_row /* kmax <= 10: [n_batches][120] row of (point pl, slot) at pl * n_local + slot, or ~0 */,
                   const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* ar, const double* campre,
                   const double* pts, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv,
-                  double* ptfac /* [n_pt][9] scratch: L^-T and L^-1 g of the damped point blocks */, double* slab, double* scal);
+                  double* ptfac /* [n_pt][12] scratch: L^-T and L^-1 g of the damped point blocks, position */, double* slab, double* scal);
 
 // Multi-rank jobs: a rank whose point elimination failed (SC_SCHUR_STATUS) turns its share of the candidate cost
 // into +inf before the scalars are summed, so every rank sees a non-finite candidate and rejects the step alike.

@@ -555,7 +555,8 @@ constexpr int kRawPieces = kRawRow / 2;           // 16-byte pieces per row
 constexpr int schur_threads(int kmax) { return kmax <= 16 ? 256 : 512; }
 constexpr int kCamTab = 10;                       // per window camera: R (9), first-order-branch flag
 constexpr int kPointVals = 12;                    // per point and batch: M = L^-T (6), t = L^-1 J_p^T r (3), position (3)
-constexpr int kPtFac = 9;                         // per point in global memory: M (6), t (3) - written by the chunk's prologue
+constexpr int kPtFac = 12;                        // per point in global memory: M (6), t (3), position (3) - 96 B, six 16-byte
+                                                  // pieces; written by the chunk's prologue
 
 typedef double schur_double4 __attribute__((ext_vector_type(4)));
 
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
                 const int idx = ptl * kPtPerLane + u, pl = idx / kPointVals, v = idx - pl * kPointVals;
                 const size_t p = (size_t)bt.p_begin + pl;
                 double val = 0.0;
-                if (pl < np) val = v < kPtFac ? ptfac[kPtFac * p + v] : pts[3 * p + (v - kPtFac)];
+                if (pl < np) val = v < 9 ? ptfac[kPtFac * p + v] : pts[3 * p + (v - 9)];
                 pre_pv[u] = val;
             }
         }
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
         for (int u = 0; u < kPtPerLane; u++) {
             const int idx = ptl * kPtPerLane + u, pl = idx / kPointVals, v = idx - pl * kPointVals;
             if (idx >= PB * kPointVals) continue;
-            double* dst = v < 6 ? cl + pl * 6 + v : v < kPtFac ? g + pl * 3 + (v - 6) : xp + pl * 3 + (v - kPtFac);
+            double* dst = v < 6 ? cl + pl * 6 + v : v < 9 ? g + pl * 3 + (v - 6) : xp + pl * 3 + (v - 9);
             *dst = pre_pv[u];
         }
     };
@@ -996,6 +997,246 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
         }
     }
     if (!rhs_in_tiles && rrow >= 0 && rrow < rows_used) out[n_pair * 36 + rrow] = racc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ba_schur10: the windowed elimination for windows of at most ten cameras (the reference's usual track length), software-
+// pipelined.  Measured on the kernel above (cycles of one batch, one workgroup, config 3): staging 400, requests 830, zeroing
+// 750, W phase 1 600, products 2 200, four barriers and their skew 1 500 - phases in a row, each bound by latency or by LDS
+// traffic (182 KB per batch: image zeroing, staged rows, the W lanes' table reads, twenty operand-block reads per k step).
+// Here the phases overlap and most of that traffic is gone:
+//   * eight waves: four PRODUCERS form the image of batch b + 1 while four CONSUMERS multiply the image of batch b - two
+//     images in LDS, ONE barrier per batch;
+//   * a producer lane pair owns one (point, window slot) pair of the batch for the whole chunk: its camera's rotation lives
+//     in registers (no camera table), its row index comes from a host-built table (pair_row; 0xFFFFFFFF: the point is not
+//     seen by that camera - the pair writes zeros, so the image is never zeroed separately), its point's factor M, t and
+//     position arrive in registers a batch ahead (no staging buffers, no intra-producer barrier);
+//   * consumers read every operand block once per k step (schur_mfma_shared4), all ten tiles whatever the window's width.
+// LDS traffic per batch: 17 KB of image writes + 45 KB of operand reads.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kS10Kmax = 10;
+constexpr int kS10PB = 12;                      // points per batch (= schur_batch_points(10))
+constexpr int kS10KB = 3 * kS10PB;              // image rows (k)
+constexpr int kS10LD = SchurShape<10>::LD;      // 80
+constexpr int kS10Threads = 512;
+constexpr size_t kS10Lds = sizeof(double) * 2 * (kS10KB * kS10LD + kS10PairsPerBatch * 6 + kS10PB * kPtFac);   // images, G, point blocks
+static_assert(kS10PairsPerBatch == kS10PB * kS10Kmax && 2 * kS10PairsPerBatch <= kS10Threads / 2, "two producer lanes per (point, slot) pair");
+
+__global__ __launch_bounds__(kS10Threads, 4) void ba_schur10_kernel(
+    const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches, const uint32_t* __restrict__ chunk_slab,
+    const uint32_t* __restrict__ chunk_cam, const uint32_t* __restrict__ pair_row, const double* __restrict__ ar,
+    const double* __restrict__ campre, const double* __restrict__ pts, const double* __restrict__ C,
+    const double* __restrict__ gp, const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv,
+    double* __restrict__ ptfac, double* __restrict__ slab, double* __restrict__ scal)
+{
+    constexpr int PB = kS10PB, KB = kS10KB, LD = kS10LD, NT = kS10Threads;
+    constexpr int kPieces = 3 * kS10PairsPerBatch;         // 16-byte pieces of the G parts of a batch's rows
+    constexpr int kPiecePasses = (kPieces + 255) / 256;    // per consumer lane
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* const img = lds;                                       // [2][KB][LD]    images, by batch parity
+    double* const gbuf = img + 2 * KB * LD;                        // [2][120][6]    G of every (point, slot) pair (zeros: not observed)
+    double* const ptbuf = gbuf + 2 * kS10PairsPerBatch * 6;        // [2][PB][12]    M, t, position of the batch's points
+    const SchurChunk ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid % 64;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / 64);
+    const int K = (int)ch.n_local, rows_used = 6 * K;
+    const int nb = (int)(ch.batch_end - ch.batch_begin);
+    if (nb <= 0) return;
+
+    // batch descriptors in registers, lane l of every wave holding batch l
+    const SchurBatch bd_mine = batches[ch.batch_begin + (uint32_t)(lane < nb ? lane : nb - 1)];
+    auto batch_at = [&](int rel) __attribute__((always_inline)) -> SchurBatch {   // rel: wave-uniform
+        if (rel >= 64) return batches[ch.batch_begin + (uint32_t)rel];
+        SchurBatch b;
+        b.q_begin = (uint32_t)__builtin_amdgcn_readlane((int)bd_mine.q_begin, rel);
+        b.q_end = (uint32_t)__builtin_amdgcn_readlane((int)bd_mine.q_end, rel);
+        b.p_begin = (uint32_t)__builtin_amdgcn_readlane((int)bd_mine.p_begin, rel);
+        b.p_end = (uint32_t)__builtin_amdgcn_readlane((int)bd_mine.p_end, rel);
+        b.full = 0;
+        return b;
+    };
+
+    // the chunk's points, all at once: M = L^-T, t = L^-1 g, C^-1 (see ba_schur_kernel); the position rides along
+    for (int base = 0; base < nb * PB; base += NT) {   // uniform trip count: every lane takes part in the lane reads
+        const int idx = base + tid;
+        const int brel = idx / PB < nb ? idx / PB : nb - 1;
+        // the batch's point range: out of a neighbour lane's descriptor registers, not out of memory
+        uint32_t b_p0 = (uint32_t)__shfl((int)bd_mine.p_begin, brel & 63, 64);
+        uint32_t b_p1 = (uint32_t)__shfl((int)bd_mine.p_end, brel & 63, 64);
+        if (brel >= 64) {
+            const SchurBatch bt = batches[ch.batch_begin + (uint32_t)brel];
+            b_p0 = bt.p_begin; b_p1 = bt.p_end;
+        }
+        const uint32_t pl = (uint32_t)(idx % PB);
+        if (idx >= nb * PB || pl >= b_p1 - b_p0) continue;
+        const size_t p = (size_t)b_p0 + pl;
+        double c[6], mt[6], ci[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) c[i] = C[6 * p + i];
+        const double g0 = gp[3 * p], g1 = gp[3 * p + 1], g2 = gp[3 * p + 2];
+        const double x0 = pts[3 * p], x1 = pts[3 * p + 1], x2 = pts[3 * p + 2];
+        const double m[6] = {c[0] + point_lambda(c[0], sp[3 * p], lm), c[1], c[2], c[3] + point_lambda(c[3], sp[3 * p + 1], lm), c[4],
+                             c[5] + point_lambda(c[5], sp[3 * p + 2], lm)};
+        if (!sym3_chol_inverse(m, mt, ci)) scal[SC_SCHUR_STATUS] = 1.0;
+        double* f = ptfac + kPtFac * p;
+        double* o = Cinv + 6 * p;
+#pragma unroll
+        for (int i = 0; i < 6; i++) { f[i] = mt[i]; o[i] = ci[i]; }
+        f[6] = mt[0] * g0;
+        f[7] = mt[1] * g0 + mt[3] * g1;
+        f[8] = mt[2] * g0 + mt[4] * g1 + mt[5] * g2;
+        f[9] = x0; f[10] = x1; f[11] = x2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // same CU, same L1: workgroup scope orders the read-back
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // Loop iteration b = -2 .. nb - 1, one barrier each:
+    //   consumers  request the rows and the point block of batch b + 2 (indices requested an iteration earlier), multiply the
+    //              image of batch b, then move what arrived to gbuf / ptbuf[b & 1] - the memory latency hides behind the
+    //              products, and the waves that are short of work carry the requests;
+    //   producers  form the image of batch b + 1 from gbuf / ptbuf[(b + 1) & 1]: LDS in, LDS out, no memory instruction.
+    if (wave < 4) {
+        // ---- producers --------------------------------------------------------------------------------------------
+        const int e = tid >> 1, half = tid & 1;            // the lane pair's (point, slot) pair; rotation rows / translation rows
+        const bool on = e < PB * K;
+        const int pl = on ? e / K : 0, slot = on ? e - pl * K : 0;
+        double R[9];
+        bool small;
+        {
+            const double* pc = campre + kPoseStride * (size_t)chunk_cam[(size_t)blockIdx.x * kS10Kmax + slot];
+#pragma unroll
+            for (int i = 0; i < 9; i++) R[i] = pc[i];
+            small = pc[21] != 0.0;
+        }
+        for (int b = -2; b < nb; b++) {
+            if (on && b + 1 >= 0 && b + 1 < nb) {
+                const int par = (b + 1) & 1;
+                const double* pb = ptbuf + par * (PB * kPtFac) + pl * kPtFac;
+                const double* gs = gbuf + par * (kS10PairsPerBatch * 6) + e * 6;
+                double* im = img + par * (KB * LD);
+                double G[6], M[6], x[3], v[3], w[18];
+#pragma unroll
+                for (int i = 0; i < 6; i++) { G[i] = gs[i]; M[i] = pb[i]; }
+#pragma unroll
+                for (int i = 0; i < 3; i++) x[i] = pb[9 + i];
+                compact_v(R, small, x, v);
+                compact_wt(G, R, v, w);
+                // U~ = W~ L^-T: rows 3 pl + c (k), columns 6 slot + 3 half + rr; t into column 6 K
+                double* Uc = im + (pl * 3) * LD + slot * 6 + half * 3;
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) {
+                    const double w0 = half ? w[(3 + rr) * 3] : w[rr * 3], w1 = half ? w[(3 + rr) * 3 + 1] : w[rr * 3 + 1],
+                                 w2 = half ? w[(3 + rr) * 3 + 2] : w[rr * 3 + 2];
+                    Uc[rr] = w0 * M[0];
+                    Uc[LD + rr] = w0 * M[1] + w1 * M[3];
+                    Uc[2 * LD + rr] = w0 * M[2] + w1 * M[4] + w2 * M[5];
+                }
+                if (slot == 0 && half == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) im[(pl * 3 + c) * LD + rows_used] = pb[6 + c];
+                }
+            }
+            lds_barrier();
+        }
+    } else {
+    // ---- consumers ----------------------------------------------------------------------------------------------------
+    const int cw = wave - 4, ct = tid - 256;
+    const int bi0 = cw == 3 ? 0 : cw, bi1 = cw == 3 ? 3 : cw + 1, bi2 = cw < 2 ? cw + 2 : 0;   // the wave's operand blocks
+    int t_i0[3], t_j0[3];
+    t_i0[0] = (cw == 3 ? 0 : cw) * 16; t_j0[0] = (cw == 3 ? 3 : cw) * 16;
+    t_i0[1] = (cw == 3 ? 3 : cw) * 16; t_j0[1] = (cw == 3 ? 3 : cw + 1) * 16;
+    t_i0[2] = cw < 2 ? cw * 16 : -1;   t_j0[2] = cw < 2 ? (cw + 2) * 16 : 0;
+    const double* x0p = img + (lane / 16) * LD + bi0 * 16 + lane % 16;
+    const double* x1p = img + (lane / 16) * LD + bi1 * 16 + lane % 16;
+    const double* x2p = img + (lane / 16) * LD + bi2 * 16 + lane % 16;
+    schur_double4 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) acc[j] = schur_double4{0.0, 0.0, 0.0, 0.0};
+    // this lane's pieces of a batch's rows: piece c = ct + 256 s of pair c / 3 (pieces past 3 * PB * K: none)
+    int pc_pair[kPiecePasses], pc_part[kPiecePasses];
+    bool pc_on[kPiecePasses];
+#pragma unroll
+    for (int s = 0; s < kPiecePasses; s++) {
+        const int c = ct + 256 * s;
+        pc_pair[s] = c / 3; pc_part[s] = c - 3 * pc_pair[s];
+        pc_on[s] = pc_pair[s] < PB * K;
+    }
+    const uint32_t* prow = pair_row + (size_t)ch.batch_begin * kS10PairsPerBatch;
+    uint32_t rowi[kPiecePasses];
+    double2 gpiece[kPiecePasses];
+    double2 ptreg = make_double2(0.0, 0.0);
+    auto load_index = [&](int rel) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < kPiecePasses; s++) rowi[s] = pc_on[s] ? prow[(size_t)rel * kS10PairsPerBatch + pc_pair[s]] : 0xFFFFFFFFu;
+    };
+    auto load_batch = [&](int rel) __attribute__((always_inline)) {   // rows through rowi (loaded for `rel`), point block
+#pragma unroll
+        for (int s = 0; s < kPiecePasses; s++) {
+            const bool has = rowi[s] != 0xFFFFFFFFu;
+            const double2 v2 = reinterpret_cast<const double2*>(ar + kArRow * (size_t)(has ? rowi[s] : 0u))[pc_part[s]];
+            gpiece[s] = has ? v2 : make_double2(0.0, 0.0);
+        }
+        if (ct < PB * 6) {
+            const SchurBatch bt = batch_at(rel);
+            const uint32_t pl6 = (uint32_t)ct / 6, piece = (uint32_t)ct - 6 * pl6;
+            const bool live = pl6 < bt.p_end - bt.p_begin;
+            const double2 v2 = reinterpret_cast<const double2*>(ptfac + kPtFac * ((size_t)bt.p_begin + (live ? pl6 : 0u)))[piece];
+            ptreg = live ? v2 : make_double2(0.0, 0.0);   // past the batch's points: zeros (t must be: the k padding of U~ t)
+        }
+    };
+    auto store_batch = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < kPiecePasses; s++)
+            if (pc_on[s]) reinterpret_cast<double2*>(gbuf + par * (kS10PairsPerBatch * 6))[ct + 256 * s] = gpiece[s];
+        if (ct < PB * 6) reinterpret_cast<double2*>(ptbuf + par * (PB * kPtFac))[ct] = ptreg;
+    };
+    load_index(0);
+    for (int b = -2; b < nb; b++) {
+        const bool more = b + 2 < nb;
+        if (more) {
+            load_batch(b + 2);
+            if (b + 3 < nb) load_index(b + 3);
+        }
+        if (b >= 0) {
+            const int off = (b & 1) * (KB * LD);
+            schur_mfma_shared4<KB, LD>(cw, x0p + off, x1p + off, x2p + off, acc);
+        }
+        if (more) store_batch(b & 1);
+        lds_barrier();
+    }
+    // the chunk's window: [pair a <= b][6x6] then [camera][6] (layout and symmetry rule as in ba_schur_kernel); column 6 K of
+    // the tiles holds U~ t.  Assembled in LDS (the images are done with) so that it leaves as one contiguous stream.
+    double* out = img;
+    const int n_pair = K * (K + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if (t_i0[j] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = t_i0[j] + 4 * r + lane / 16, col = t_j0[j] + lane % 16;
+            if (col == rows_used && row < rows_used) out[n_pair * 36 + row] = acc[j][r];
+            if (row >= rows_used || col >= rows_used) continue;
+            const int a = row / 6, rr = row - 6 * a, b = col / 6, cc = col - 6 * b;
+            if (a > b) continue;
+            const int pidx = a * K - a * (a - 1) / 2 + (b - a);
+            double* blk = out + pidx * 36;
+            const double v = acc[j][r];
+            if (a < b) {
+                blk[rr * 6 + cc] = v;
+            } else if (row <= col) {
+                blk[rr * 6 + cc] = v;
+                if (row < col) blk[cc * 6 + rr] = v;
+            }
+        }
+    }
+    }
+    lds_barrier();
+    {
+        double* dst = slab + chunk_slab[blockIdx.x];
+        const int n_out = K * (K + 1) / 2 * 36 + rows_used;
+        for (int i = tid; i < n_out; i += NT) dst[i] = img[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1404,18 +1645,16 @@ void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacob
 }
 
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
-                  const uint32_t* chunk_slab, const uint32_t* chunk_cam, const uint32_t* pt_obs, const uint32_t* q_pt,
+                  const uint32_t* chunk_slab, const uint32_t* chunk_cam, const uint32_t* pair_row, const uint32_t* pt_obs, const uint32_t* q_pt,
                   const uint8_t* q_slot, const double* ar, const double* campre, const double* pts, const double* C, const double* gp,
                   const double* sp, LmDiag lm, double* Cinv, double* ptfac, double* slab, double* scal)
 {
     if (!n_chunks) return;
     if (kmax <= 10) {
-        // windows of at most 10 cameras (60 rows: four 16-row tiles, ten of them in the upper triangle, three per wave):
-        // the common case of the reference's tracks; 32 KB of LDS and at most 168 registers - three workgroups per CU
-        constexpr size_t lds = SchurShape<10>::lds_bytes;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ba_schur_kernel<10>), dim3(n_chunks), dim3(schur_threads(10)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
-                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
+        // windows of at most 10 cameras: the pipelined kernel (46 KB of LDS, two workgroups of eight waves per CU)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur10_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS10Lds);
+        hipLaunchKernelGGL(ba_schur10_kernel, dim3(n_chunks), dim3(kS10Threads), kS10Lds, s, chunks, batches, chunk_slab, chunk_cam, pair_row, ar,
+                           campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
     } else if (kmax <= 16) {
         constexpr size_t lds = SchurShape<16>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -85,6 +85,7 @@ struct soslam_ba {
     DevBuf<double> slab;
     DevBuf<SchurChunk> chunks;
     DevBuf<SchurBatch> batches;
+    DevBuf<uint32_t> pair_row;
     // long-track points (beyond the Schur window / batch limits)
     DevBuf<LongPoint> long_pts;
     DevBuf<uint32_t> lo_row, lo_cam, lo_cam_off, pair_a, pair_b, pair_off;
@@ -451,6 +452,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     if (const char* e = std::getenv("SOSLAM_CHUNK_PTS")) chunk_pts_max = (uint32_t)std::max(1, std::atoi(e));   // development
     std::vector<SchurChunk> chunks;
     std::vector<SchurBatch> batches;
+    std::vector<uint32_t> pair_row;                         // kmax <= 10: [batch][120], see launch_schur
     std::vector<uint32_t> chunk_slab;                       // offset of each chunk's window in the slab
     std::vector<uint32_t> chunk_cam;                        // [chunk][K] camera of each window slot
     std::vector<std::vector<uint32_t>> blk_contrib(h->n_blocks), cam_contrib(nf);
@@ -485,6 +487,17 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                     if (f < 0) continue;
                     while (local[sl] < (uint32_t)f) sl++;
                     q_slot[q] = (uint8_t)sl;
+                }
+            }
+            if (K <= 10) {
+                // the ten-camera kernel's table: the compact row of every (point, window slot) pair of every batch
+                pair_row.resize(batches.size() * (size_t)kS10PairsPerBatch, 0xFFFFFFFFu);
+                const uint32_t KL = (uint32_t)local.size();
+                for (uint32_t b = ch.batch_begin; b < ch.batch_end; b++) {
+                    const SchurBatch& bt = batches[b];
+                    for (uint32_t pp = bt.p_begin; pp < bt.p_end; pp++)
+                        for (uint32_t q = pt_start[pp]; q < pt_start[pp + 1]; q++)
+                            if (q_slot[q] != 255) pair_row[(size_t)b * kS10PairsPerBatch + (pp - bt.p_begin) * KL + q_slot[q]] = pt_obs[q];
                 }
             }
             for (uint32_t b = ch.batch_begin; b < ch.batch_end; b++) {
@@ -619,6 +632,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->q_slot.upload(q_slot, s));
     SOSLAM_CHECK(h->chunks.upload(chunks, s));
     SOSLAM_CHECK(h->batches.upload(batches, s));
+    SOSLAM_CHECK(h->pair_row.upload(pair_row, s));
     SOSLAM_CHECK(h->chunk_slab.upload(chunk_slab, s));
     SOSLAM_CHECK(h->chunk_cam.upload(chunk_cam, s));
     SOSLAM_CHECK(h->free_cam.upload(free_cam, s));
@@ -664,7 +678,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->gp.alloc((size_t)n_pt * 3));
     SOSLAM_CHECK(h->sp.alloc((size_t)n_pt * 3));
     SOSLAM_CHECK(h->Cinv.alloc((size_t)n_pt * 6));
-    SOSLAM_CHECK(h->ptfac.alloc((size_t)n_pt * 9));
+    SOSLAM_CHECK(h->ptfac.alloc((size_t)n_pt * 12));   // kPtFac doubles per point
     SOSLAM_CHECK(h->B.alloc((size_t)nf * 36));
     SOSLAM_CHECK(h->gc.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->sc.alloc((size_t)nf * 6));
@@ -835,7 +849,7 @@ BsrView bsr_view(const soslam_ba* h)
 void run_schur(soslam_ba* h, const LmDiag& lm)
 {
     hipStream_t s = h->stream;
-    launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pt_obs.p, h->q_pt.p,
+    launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pair_row.p, h->pt_obs.p, h->q_pt.p,
                  h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p, h->scalp());
     launch_schur_long(s, h->n_long, h->long_pts.p, h->lo_row.p, h->lo_cam.p, h->lo_cam_off.p, h->n_long_pairs, h->pair_a.p, h->pair_b.p,
                       h->pair_off.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->long_wy.p,
@@ -1721,7 +1735,7 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
             launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->C.p, h->gp.p);
             break;
         case SOSLAM_KERNEL_SCHUR:
-            launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pt_obs.p, h->q_pt.p,
+            launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pair_row.p, h->pt_obs.p, h->q_pt.p,
                          h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p,
                          h->scalp());
             break;
