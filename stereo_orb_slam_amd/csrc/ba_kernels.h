@@ -142,8 +142,10 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
                   const uint32_t* chunk_slab, const uint32_t* chunk_cam /* [n_chunks][kmax] camera of each window slot */,
                   const uint32_t* pair_row /* kmax <= 10: [n_batches][120] row of (point pl, slot) at pl * n_local + slot, or ~0 */,
                   const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* ar, const double* campre,
-                  const double* pts, const double* C, const double* gp, const double* sp, LmDiag lm, double* Cinv,
-                  double* ptfac /* [n_pt][12] scratch: L^-T and L^-1 g of the damped point blocks, position */, double* slab, double* scal);
+                  const double* pts, double* C, double* gp, const double* sp, LmDiag lm, double* Cinv,
+                  double* ptfac /* [n_pt][12] scratch: L^-T and L^-1 g of the damped point blocks, position */, double* slab, double* scal,
+                  const uint32_t* pt_start, const uint32_t* q_cam,
+                  int point_blocks_from_rows /* kmax <= 10 only: the kernel forms C and gp itself (and writes them): no launch_point_reduce needed */);
 
 // Multi-rank jobs: a rank whose point elimination failed (SC_SCHUR_STATUS) turns its share of the candidate cost
 // into +inf before the scalars are summed, so every rank sees a non-finite candidate and rejects the step alike.

@@ -636,7 +636,7 @@ __device__ __forceinline__ void schur_mfma_dispatch(int n_act, const double* con
     }
 }
 
-// Full four-tile-row windows on four waves (nine or ten cameras - the reference's usual track length): the ten tiles are dealt
+// Four tile rows on four waves (windows of up to ten cameras - the reference's usual track length; ba_schur10_kernel): the ten tiles are dealt
 // so that a wave's tiles share operand blocks, and each 16-column block of the image is read ONCE per k step and wave and
 // used in every product it appears in (an operand block is the same data whether it feeds A or B):
 //   wave 0: (0,0) (0,1) (0,2)   blocks 0 1 2        wave 2: (2,2) (2,3)   blocks 2 3
@@ -773,21 +773,6 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
             t_i0[j] = ti * 16; t_j0[j] = (ti + u) * 16;
         }
         acc[j] = schur_double4{0.0, 0.0, 0.0, 0.0};
-    }
-    // the operand-sharing deal of full four-row windows (see schur_mfma_shared4)
-    const bool shared4 = NT1 == 4 && NT == 256 && TPW == 3 && nt1_used == 4;
-    const double* xp[3] = {Ui, Ui, Ui};
-    if constexpr (TPW == 3) {
-        if (shared4) {
-            const int bi0 = wave == 3 ? 0 : wave;                       // the wave's blocks
-            const int bi1 = wave == 3 ? 3 : wave + 1, bi2 = wave + 2;   // (bi2 only on waves 0 and 1)
-            t_i0[0] = (wave == 3 ? 0 : wave) * 16; t_j0[0] = (wave == 3 ? 3 : wave) * 16;
-            t_i0[1] = (wave == 3 ? 3 : wave) * 16; t_j0[1] = (wave == 3 ? 3 : wave + 1) * 16;
-            t_i0[2] = wave < 2 ? wave * 16 : -1;   t_j0[2] = wave < 2 ? (wave + 2) * 16 : 0;
-            xp[0] = Ui + (lane / 16) * LD + bi0 * 16 + lane % 16;
-            xp[1] = Ui + (lane / 16) * LD + bi1 * 16 + lane % 16;
-            xp[2] = Ui + (lane / 16) * LD + (wave < 2 ? bi2 : 0) * 16 + lane % 16;
-        }
     }
     // operand bases of the wave's tiles in the image (fixed for the chunk) and the number of tiles it owns
     const double* pa[TPW];
@@ -944,12 +929,7 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
         // window += Ui^T Ui over the batch's columns: lane l feeds A[i = l%16][k = l/16] and B[k = l/16][j = l%16], both
         // from the one image.  Straight-line code: the wave's n_act tiles (wave-uniform) pick one fully unrolled body, all
         // KB / 4 steps are taken (the k padding of a short batch is zero), every operand read is base + immediate offset
-        if constexpr (TPW == 3) {
-            if (shared4) schur_mfma_shared4<KB, LD>(wave, xp[0], xp[1], xp[2], acc);
-            else schur_mfma_dispatch<TPW, KB, LD>(n_act, pa, pb, acc);
-        } else {
-            schur_mfma_dispatch<TPW, KB, LD>(n_act, pa, pb, acc);
-        }
+        schur_mfma_dispatch<TPW, KB, LD>(n_act, pa, pb, acc);
         // rhs part U~ t: all KB columns, straight-line (the k padding of a short batch is zero in both factors), every operand
         // requested before the first product
         if (!rhs_in_tiles && rrow >= 0 && rrow < rows_used) {
@@ -1019,15 +999,16 @@ constexpr int kS10PB = 12;                      // points per batch (= schur_bat
 constexpr int kS10KB = 3 * kS10PB;              // image rows (k)
 constexpr int kS10LD = SchurShape<10>::LD;      // 80
 constexpr int kS10Threads = 512;
-constexpr size_t kS10Lds = sizeof(double) * 2 * (kS10KB * kS10LD + kS10PairsPerBatch * 6 + kS10PB * kPtFac);   // images, G, point blocks
+constexpr size_t kS10Lds = sizeof(double) * (2 * (kS10KB * kS10LD + kS10PairsPerBatch * 6 + kS10PB * kPtFac) + kS10Kmax * 9);   // images, G, point blocks, rotations
 static_assert(kS10PairsPerBatch == kS10PB * kS10Kmax && 2 * kS10PairsPerBatch <= kS10Threads / 2, "two producer lanes per (point, slot) pair");
 
 __global__ __launch_bounds__(kS10Threads, 4) void ba_schur10_kernel(
     const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches, const uint32_t* __restrict__ chunk_slab,
     const uint32_t* __restrict__ chunk_cam, const uint32_t* __restrict__ pair_row, const double* __restrict__ ar,
-    const double* __restrict__ campre, const double* __restrict__ pts, const double* __restrict__ C,
-    const double* __restrict__ gp, const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv,
-    double* __restrict__ ptfac, double* __restrict__ slab, double* __restrict__ scal)
+    const double* __restrict__ campre, const double* __restrict__ pts, double* __restrict__ C,
+    double* __restrict__ gp, const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv,
+    double* __restrict__ ptfac, double* __restrict__ slab, double* __restrict__ scal, const uint32_t* __restrict__ pt_start,
+    const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_cam, const uint8_t* __restrict__ q_slot, const int from_rows)
 {
     constexpr int PB = kS10PB, KB = kS10KB, LD = kS10LD, NT = kS10Threads;
     constexpr int kPieces = 3 * kS10PairsPerBatch;         // 16-byte pieces of the G parts of a batch's rows
@@ -1036,6 +1017,7 @@ __global__ __launch_bounds__(kS10Threads, 4) void ba_schur10_kernel(
     double* const img = lds;                                       // [2][KB][LD]    images, by batch parity
     double* const gbuf = img + 2 * KB * LD;                        // [2][120][6]    G of every (point, slot) pair (zeros: not observed)
     double* const ptbuf = gbuf + 2 * kS10PairsPerBatch * 6;        // [2][PB][12]    M, t, position of the batch's points
+    double* const camtab = ptbuf + 2 * PB * kPtFac;                // [K][9]         rotations of the window's cameras (point pass)
     const SchurChunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid % 64;
     const int wave = __builtin_amdgcn_readfirstlane(tid / 64);
@@ -1056,9 +1038,16 @@ __global__ __launch_bounds__(kS10Threads, 4) void ba_schur10_kernel(
         return b;
     };
 
-    // the chunk's points, all at once: M = L^-T, t = L^-1 g, C^-1 (see ba_schur_kernel); the position rides along
-    for (int base = 0; base < nb * PB; base += NT) {   // uniform trip count: every lane takes part in the lane reads
-        const int idx = base + tid;
+    if (from_rows) {
+        for (int e = tid; e < K * 9; e += NT) camtab[e] = campre[kPoseStride * (size_t)chunk_cam[(size_t)blockIdx.x * kS10Kmax + e / 9] + e % 9];
+        __syncthreads();
+    }
+    // The chunk's points, all at once, a lane pair each: J_p^T J_p = sum R^T G R and J_p^T r = sum R^T h over the point's compact
+    // rows when from_rows is set (what ba_point_reduce does in a launch of its own - its 19 us are saved whenever the
+    // linearisation behind an accepted step needs no point pass for anything else; the rows come back out of the L2 for the
+    // pipeline below), else read from C / gp; then M = L^-T, t = L^-1 g, C^-1 (see ba_schur_kernel); the position rides along.
+    for (int base = 0; base < 2 * nb * PB; base += NT) {   // uniform trip count: every lane takes part in the lane reads
+        const int idx = (base + tid) >> 1, sub = tid & 1;
         const int brel = idx / PB < nb ? idx / PB : nb - 1;
         // the batch's point range: out of a neighbour lane's descriptor registers, not out of memory
         uint32_t b_p0 = (uint32_t)__shfl((int)bd_mine.p_begin, brel & 63, 64);
@@ -1068,13 +1057,78 @@ __global__ __launch_bounds__(kS10Threads, 4) void ba_schur10_kernel(
             b_p0 = bt.p_begin; b_p1 = bt.p_end;
         }
         const uint32_t pl = (uint32_t)(idx % PB);
-        if (idx >= nb * PB || pl >= b_p1 - b_p0) continue;
-        const size_t p = (size_t)b_p0 + pl;
-        double c[6], mt[6], ci[6];
+        const bool live = idx < nb * PB && pl < b_p1 - b_p0;
+        const size_t p = (size_t)b_p0 + (live ? pl : 0u);
+        double c[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        if (from_rows) {
+            if (live) {
+                // the lane's observations (every second one of the point): all their indices in one go, then the rows three at
+                // a time, then the arithmetic - three memory round trips for a ten-camera track; the window cameras'
+                // rotations come from the table in LDS (slot 255: a fixed camera, not in the window - from memory)
+                constexpr int kIdx = 6, kRows = 3;
+                const uint32_t q1 = pt_start[p + 1];
+                for (uint32_t q0 = pt_start[p] + (uint32_t)sub; q0 < q1; q0 += 2 * kIdx) {
+                    uint32_t rk[kIdx], rs[kIdx];
 #pragma unroll
-        for (int i = 0; i < 6; i++) c[i] = C[6 * p + i];
-        const double g0 = gp[3 * p], g1 = gp[3 * p + 1], g2 = gp[3 * p + 2];
+                    for (int u = 0; u < kIdx; u++) {
+                        const uint32_t q = q0 + 2 * u;
+                        rk[u] = q < q1 ? pt_obs[q] : 0xFFFFFFFFu;
+                        rs[u] = q < q1 ? (uint32_t)q_slot[q] | (q_cam[q] << 8) : 0u;
+                    }
+#pragma unroll
+                    for (int u0 = 0; u0 < kIdx; u0 += kRows) {
+                        double2 rw[kRows][5];
+#pragma unroll
+                        for (int u = 0; u < kRows; u++) {
+                            const double2* row = reinterpret_cast<const double2*>(ar + kArRow * (size_t)(rk[u0 + u] != 0xFFFFFFFFu ? rk[u0 + u] : 0u));
+#pragma unroll
+                            for (int i = 0; i < 5; i++) rw[u][i] = row[i];
+                        }
+#pragma unroll
+                        for (int u = 0; u < kRows; u++) {
+                            if (rk[u0 + u] == 0xFFFFFFFFu) continue;
+                            const uint32_t slot = rs[u0 + u] & 255u;
+                            const double* Rp = slot != 255u ? camtab + slot * 9 : campre + kPoseStride * (size_t)(rs[u0 + u] >> 8);
+                            double w[10], R[9], z[9];
+#pragma unroll
+                            for (int i = 0; i < 5; i++) { w[2 * i] = rw[u][i].x; w[2 * i + 1] = rw[u][i].y; }
+#pragma unroll
+                            for (int i = 0; i < 9; i++) R[i] = Rp[i];
+                            compact_gr(w, R, z);                       // Z = G R;  J_p^T J_p = R^T Z,  J_p^T r = R^T h
+                            c[0] += R[0] * z[0] + R[3] * z[3] + R[6] * z[6];
+                            c[1] += R[0] * z[1] + R[3] * z[4] + R[6] * z[7];
+                            c[2] += R[0] * z[2] + R[3] * z[5] + R[6] * z[8];
+                            c[3] += R[1] * z[1] + R[4] * z[4] + R[7] * z[7];
+                            c[4] += R[1] * z[2] + R[4] * z[5] + R[7] * z[8];
+                            c[5] += R[2] * z[2] + R[5] * z[5] + R[8] * z[8];
+                            g[0] += R[0] * w[6] + R[3] * w[7] + R[6] * w[8];
+                            g[1] += R[1] * w[6] + R[4] * w[7] + R[7] * w[8];
+                            g[2] += R[2] * w[6] + R[5] * w[7] + R[8] * w[8];
+                        }
+                    }
+                }
+            }
+            // the pair's halves (every lane takes part; lanes without a point carry zeros)
+#pragma unroll
+            for (int i = 0; i < 6; i++) c[i] += mov_dpp_f64<kDppXor1>(c[i]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) g[i] += mov_dpp_f64<kDppXor1>(g[i]);
+        } else if (live) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c[i] = C[6 * p + i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) g[i] = gp[3 * p + i];
+        }
+        if (!live || sub != 0) continue;
+        if (from_rows) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) C[6 * p + i] = c[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) gp[3 * p + i] = g[i];
+        }
+        const double g0 = g[0], g1 = g[1], g2 = g[2];
         const double x0 = pts[3 * p], x1 = pts[3 * p + 1], x2 = pts[3 * p + 2];
+        double mt[6], ci[6];
         const double m[6] = {c[0] + point_lambda(c[0], sp[3 * p], lm), c[1], c[2], c[3] + point_lambda(c[3], sp[3 * p + 1], lm), c[4],
                              c[5] + point_lambda(c[5], sp[3 * p + 2], lm)};
         if (!sym3_chol_inverse(m, mt, ci)) scal[SC_SCHUR_STATUS] = 1.0;
@@ -1646,15 +1700,16 @@ void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacob
 
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
                   const uint32_t* chunk_slab, const uint32_t* chunk_cam, const uint32_t* pair_row, const uint32_t* pt_obs, const uint32_t* q_pt,
-                  const uint8_t* q_slot, const double* ar, const double* campre, const double* pts, const double* C, const double* gp,
-                  const double* sp, LmDiag lm, double* Cinv, double* ptfac, double* slab, double* scal)
+                  const uint8_t* q_slot, const double* ar, const double* campre, const double* pts, double* C, double* gp,
+                  const double* sp, LmDiag lm, double* Cinv, double* ptfac, double* slab, double* scal, const uint32_t* pt_start,
+                  const uint32_t* q_cam, int point_blocks_from_rows)
 {
     if (!n_chunks) return;
     if (kmax <= 10) {
         // windows of at most 10 cameras: the pipelined kernel (46 KB of LDS, two workgroups of eight waves per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur10_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS10Lds);
         hipLaunchKernelGGL(ba_schur10_kernel, dim3(n_chunks), dim3(kS10Threads), kS10Lds, s, chunks, batches, chunk_slab, chunk_cam, pair_row, ar,
-                           campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
+                           campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal, pt_start, pt_obs, q_cam, q_slot, point_blocks_from_rows);
     } else if (kmax <= 16) {
         constexpr size_t lds = SchurShape<16>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -131,6 +131,7 @@ struct soslam_ba {
     // trust region
     double radius = 0.0, decrease_factor = 2.0, x_cost = 0.0;
     bool linearized = false, scale_init = false;
+    bool pt_blocks_valid = false;       // C / gp belong to the compact rows held (else the ten-camera Schur kernel forms them itself)
     bool x_cost_known = false;          // x_cost is the cost at cams[cur], pts[cur] (accepted candidates: no sum over the tiles needed)
     bool campre_current = false;        // campre already holds the pose table of cams[cur] (set on acceptance, used once by linearize)
     bool points_only_ready = false;     // structure-only path: both pose tables / camera buffers hold the constant poses, dc_full is zero
@@ -744,6 +745,11 @@ bool points_only(const soslam_ba* h) { return h->n_free == 0 && h->n_pt > 0 && h
 
 // residuals, Jacobians and the J^T J / J^T r blocks at the current state.  in_lm_loop: called by the LM loop, which on
 // the structure-only path needs no linearisation of its own (every ba_points_step launch linearises at its x)
+// The ten-camera Schur kernel can form the point blocks C = sum J_p^T J_p, g_p = sum J_p^T r itself (every point goes
+// through it: no long tracks, windows of at most ten cameras): ba_point_reduce then runs only where something else
+// needs its output first - the Jacobi scales of the first linearisation.
+bool points_fused(const soslam_ba* h) { return h->kmax <= 10 && h->n_long == 0 && h->n_chunks > 0 && !points_only(h); }
+
 int linearize(soslam_ba* h, bool in_lm_loop = false)
 {
     hipStream_t s = h->stream;
@@ -760,10 +766,13 @@ int linearize(soslam_ba* h, bool in_lm_loop = false)
         // ranks); summed from the tiles only for a state the loop has not evaluated yet
         if (!h->x_cost_known) launch_sum_strided(s, h->tile_part.p, h->n_tiles, kTileVals, 27, 0.5, h->scalp() + SC_COST_X);
     }
-    {
+    if (!points_fused(h) || !h->scale_init) {
         StageScope sc(h, SOSLAM_STAGE_POINT_REDUCE);
         launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->C.p, h->gp.p);
         if (!h->scale_init) launch_point_scale(s, h->n_pt, h->C.p, h->opt.jacobi_scaling, h->sp.p);
+        h->pt_blocks_valid = true;
+    } else {
+        h->pt_blocks_valid = false;   // the ten-camera Schur kernel forms C and gp from the rows (see launch_schur)
     }
     SOSLAM_HIP_CHECK(hipGetLastError());
     h->linearized = true;
@@ -850,7 +859,9 @@ void run_schur(soslam_ba* h, const LmDiag& lm)
 {
     hipStream_t s = h->stream;
     launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pair_row.p, h->pt_obs.p, h->q_pt.p,
-                 h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p, h->scalp());
+                 h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p, h->scalp(),
+                 h->pt_start.p, h->q_cam.p, h->pt_blocks_valid ? 0 : 1);
+    h->pt_blocks_valid = true;
     launch_schur_long(s, h->n_long, h->long_pts.p, h->lo_row.p, h->lo_cam.p, h->lo_cam_off.p, h->n_long_pairs, h->pair_a.p, h->pair_b.p,
                       h->pair_off.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->long_wy.p,
                       h->slab.p, h->scalp());
@@ -1006,7 +1017,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                              h->opt.huber_delta, h->ar.p, h->tile_part.p, gate);
             launch_cam_reduce(s, h->n_cam, h->cam_tile_start.p, h->cam_free.p, h->tile_part.p, h->campre_c.p, h->B.p, h->gc.p, gate);
         }
-        {
+        if (!points_fused(h)) {
             StageScope sc(h, SOSLAM_STAGE_POINT_REDUCE);
             launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre_c.p, h->C.p, h->gp.p, gate);
         }
@@ -1367,6 +1378,7 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
             h->x_cost = sc.cand_cost;
             h->x_cost_known = true;
             if (dev_linearized) {
+                if (points_fused(h)) h->pt_blocks_valid = false;   // no point pass behind the gate: the Schur kernel forms C, g_p
                 dev_linearized = false;      // consumed: B, g_c, C, g_p and the compact rows are those of the new point
                 h->campre_current = false;
                 h->linearized = true;
@@ -1737,7 +1749,7 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
         case SOSLAM_KERNEL_SCHUR:
             launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pair_row.p, h->pt_obs.p, h->q_pt.p,
                          h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p,
-                         h->scalp());
+                         h->scalp(), h->pt_start.p, h->q_cam.p, points_fused(h) ? 1 : 0);
             break;
         case SOSLAM_KERNEL_BACKSUB:
             launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->dcw.p, h->Cinv.p,
