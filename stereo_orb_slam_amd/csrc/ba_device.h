@@ -300,6 +300,24 @@ __device__ __forceinline__ bool sym3_inverse(const double* __restrict__ m, doubl
     return ok;
 }
 
+// the same with the reciprocal of the determinant from v_rcp_f64 and two Newton steps instead of the IEEE division sequence
+// (div_scale / div_fmas / div_fixup: a dozen dependent instructions on the critical path of every pivot step of cr_invert).
+// The result is within a few ulp of the correctly rounded one; the factor it feeds is an exact preconditioner either way.
+__device__ __forceinline__ bool sym3_inverse_fast(const double* __restrict__ m, double* __restrict__ inv)
+{
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    const double m2 = a * d - b * b;
+    const bool ok = (det > 0.0) && (a > 0.0) && (m2 > 0.0);
+    double id = __builtin_amdgcn_rcp(det);
+    id = id * (2.0 - det * id);
+    id = id * (2.0 - det * id);
+    inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+    inv[3] = (a * f - c * c) * id; inv[4] = (b * c - a * e) * id; inv[5] = m2 * id;
+    return ok;
+}
+
 // Cholesky factor C = L L^T of a symmetric positive definite 3x3 (xx xy xz yy yz zz).  Out: mt = M = L^-T (upper
 // triangular: m00 m01 m02 m11 m12 m22) and inv = C^-1 = M M^T.  ok = false when a pivot is not positive.
 __device__ __forceinline__ bool sym3_chol_inverse(const double* __restrict__ m, double* __restrict__ mt, double* __restrict__ inv)

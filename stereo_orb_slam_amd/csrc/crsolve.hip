@@ -175,8 +175,17 @@ __global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrVie
         // lane groups (rows taken from differently rounded inverses make the sweep inconsistent - measured: four
         // digits of the factor lost).  r0 r1 r2 = row lk of P^-1.
         const double m[6] = {strip[k0], strip[k0 + 1], strip[k0 + 2], strip[64 + k0 + 1], strip[64 + k0 + 2], strip[128 + k0 + 2]};
+        // every strip value this step needs is requested here, in front of the inverse's dependent chain (the compiler
+        // otherwise places the operand reads behind it: three more LDS round trips on the critical path of the step)
+        double sv[4][3];
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++) {
+            const int j = 16 * tj + lr;
+            sv[tj][0] = strip[zr0 + j]; sv[tj][1] = strip[zr1 + j]; sv[tj][2] = strip[zr2 + j];
+        }
+        const double av_strip = strip[lk * 64 + 16 * wave + lr];
         double Pi[6];
-        ok = sym3_inverse(m, Pi) && ok;     // xx xy xz yy yz zz
+        ok = sym3_inverse_fast(m, Pi) && ok;     // xx xy xz yy yz zz
         const double r0 = lk == 0 ? Pi[0] : lk == 1 ? Pi[1] : Pi[2];
         const double r1 = lk == 0 ? Pi[1] : lk == 1 ? Pi[3] : Pi[4];
         const double r2 = lk == 0 ? Pi[2] : lk == 1 ? Pi[4] : Pi[5];
@@ -184,14 +193,14 @@ __global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrVie
         double aop;
         {
             const int i = 16 * wave + lr, ci = i - k0;
-            const double av = strip[lk * 64 + i];
+            const double av = av_strip;
             aop = i < k0 ? av : -av;
             if (ci >= 0 && ci < 3) aop = lk == ci ? 1.0 : 0.0;
         }
 #pragma unroll
         for (int tj = 0; tj < 4; tj++) {
             const int j = 16 * tj + lr;
-            double bop = r0 * strip[zr0 + j] + r1 * strip[zr1 + j] + r2 * strip[zr2 + j];
+            double bop = r0 * sv[tj][0] + r1 * sv[tj][1] + r2 * sv[tj][2];
             double4_t base = acc[tj];
             const bool tile_has_pcol = k0 + 2 >= 16 * tj && k0 < 16 * tj + 16;   // static
             if (tile_has_pcol) {
