@@ -748,7 +748,11 @@ bool points_only(const soslam_ba* h) { return h->n_free == 0 && h->n_pt > 0 && h
 // The ten-camera Schur kernel can form the point blocks C = sum J_p^T J_p, g_p = sum J_p^T r itself (every point goes
 // through it: no long tracks, windows of at most ten cameras): ba_point_reduce then runs only where something else
 // needs its output first - the Jacobi scales of the first linearisation.
-bool points_fused(const soslam_ba* h) { return h->kmax <= 10 && h->n_long == 0 && h->n_chunks > 0 && !points_only(h); }
+bool points_fused(const soslam_ba* h)
+{
+    static const bool off = std::getenv("SOSLAM_NO_POINT_FUSE") != nullptr;   // development / tests: always the separate point pass
+    return !off && h->kmax <= 10 && h->n_long == 0 && h->n_chunks > 0 && !points_only(h);
+}
 
 int linearize(soslam_ba* h, bool in_lm_loop = false)
 {

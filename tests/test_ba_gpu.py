@@ -778,3 +778,35 @@ def test_line_search_on_the_bounded_problem(gpu, oracle_lib, prob1, solver):
     np.testing.assert_allclose([e.cost for e in log], [e.cost for e in olog], rtol=1e-7)
     np.testing.assert_allclose([e.step_norm for e in log[1:]], [e.step_norm for e in olog[1:]], rtol=1e-5)
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+
+
+def test_point_blocks_formed_by_the_schur_kernel_match_the_separate_point_pass(gpu):
+    """Windows of at most ten cameras go through ba_schur10, whose prologue forms the point blocks C = sum R^T G R and
+    g_p = sum R^T h from the compact rows itself, so that the linearisation behind an accepted step launches no
+    ba_point_reduce.  The same solve with the development switch SOSLAM_NO_POINT_FUSE (a separate point
+    pass after every linearisation, as before) must give the same trajectory: the two differ only in the order in which a
+    point's observations are added (two lanes per point against four)."""
+    import json
+    import subprocess
+    import sys
+    ba, synth, L = gpu
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys; sys.path.insert(0, %r)\n"
+            "from stereo_orb_slam_amd import ba, synth\n"
+            "p = synth.generate_ba(2)\n"
+            "with ba.BundleAdjustment(ba.default_options(linear_solver=2, max_iterations=8, check_termination=0)) as h:\n"
+            "    h.load(p); s = h.solve(); log = h.iteration_log(); cams, pts = h.get_state()\n"
+            "print(json.dumps({'cost': [e.cost for e in log], 'acc': [e.accepted for e in log], 'final': s.final_cost,\n"
+            "                  'cams': cams.ravel().tolist()[:60], 'pts': pts.ravel().tolist()[:60]}))\n") % root
+    outs = []
+    for env_extra in ({}, {"SOSLAM_NO_POINT_FUSE": "1"}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    fused, separate = outs
+    assert fused["acc"] == separate["acc"]
+    np.testing.assert_allclose(fused["cost"], separate["cost"], rtol=1e-11)
+    np.testing.assert_allclose(fused["final"], separate["final"], rtol=1e-11)
+    np.testing.assert_allclose(fused["cams"], separate["cams"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(fused["pts"], separate["pts"], rtol=1e-8, atol=1e-10)
