@@ -810,3 +810,30 @@ def test_point_blocks_formed_by_the_schur_kernel_match_the_separate_point_pass(g
     np.testing.assert_allclose(fused["final"], separate["final"], rtol=1e-11)
     np.testing.assert_allclose(fused["cams"], separate["cams"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(fused["pts"], separate["pts"], rtol=1e-8, atol=1e-10)
+
+
+def test_schur_chunks_longer_than_the_descriptor_registers(gpu):
+    """ba_schur10 keeps a chunk's batch descriptors in registers, lane l holding batch l, and reads them from memory past 64
+    batches.  Ten cameras seeing all of 3 000 points, split into chunks of 1 024 points (86 batches; development switch
+    SOSLAM_CHUNK_PTS) and into the default small chunks, must follow the same trajectory."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys; sys.path.insert(0, %r)\n"
+            "from stereo_orb_slam_amd import ba, synth\n"
+            "p = synth.generate_ba(None, n_cam=10, n_pt=3000, track_mode=0, track_len=10)\n"
+            "with ba.BundleAdjustment(ba.default_options(max_iterations=6, check_termination=0)) as h:\n"
+            "    h.load(p); s = h.solve(); log = h.iteration_log(); cams, pts = h.get_state()\n"
+            "print(json.dumps({'cost': [e.cost for e in log], 'acc': [e.accepted for e in log], 'final': s.final_cost,\n"
+            "                  'cams': cams.ravel().tolist(), 'pts': pts.ravel().tolist()[:90]}))\n") % root
+    outs = []
+    for env_extra in ({}, {"SOSLAM_CHUNK_PTS": "1024"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    small, long_ = outs
+    assert small["acc"] == long_["acc"] and len(small["cost"]) >= 4
+    np.testing.assert_allclose(small["cost"], long_["cost"], rtol=1e-11)
+    np.testing.assert_allclose(small["cams"], long_["cams"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(small["pts"], long_["pts"], rtol=1e-8, atol=1e-10)
