@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "ba_kernels.h"
+#include "reduce.h"
 
 namespace soslam {
 
@@ -128,31 +129,12 @@ __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blo
 //     -A_iK P^-1, the pivot block P^-1, everything else A_ij - A_iK P^-1 A_Kj.
 constexpr int kCrInvertThreads = 256;
 
+// The sweep proper: the 64 x 64 image in the accumulator registers of four waves (wave w: tile row w), in place.  strips:
+// [buffer 2][pivot row c, 3 = zeros][column 64] in LDS.  Returns false when a pivot block was not positive definite.
 template <int NSTEPS>
-__global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrView v, const uint32_t h, const int final_node,
-                                                                     double* __restrict__ scal)
+__device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4][64], const int wave, const int lane)
 {
-    __shared__ double strips[2][4][64];   // [buffer][pivot row c, 3 = zeros][column]
-    __shared__ double X[64 * kLd];
-    const int sb = v.sb;
-    const int lane = threadIdx.x % 64, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
     const int lr = lane % 16, lk = lane / 16;
-    const size_t sb2 = (size_t)sb * sb;
-    const uint32_t node = final_node ? 0u : h * (2 * blockIdx.x + 1);
-    if (node >= v.m) return;
-
-    double4_t acc[4];
-    {
-        const double* src = v.D + node * sb2;
-#pragma unroll
-        for (int tj = 0; tj < 4; tj++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int i = 16 * wave + 4 * r + lk, j = 16 * tj + lr;
-                acc[tj][r] = (i < sb && j < sb) ? src[(size_t)i * sb + j] : (i == j ? 1.0 : 0.0);   // identity padding: extra steps are harmless
-            }
-    }
-
     // Lane group lk = l/16 feeds k = lk of both operands; group 3 (the padding k = 3) reads a strip row of zeros.
     const int zr0 = (lk < 3 ? 0 : 3) * 64, zr1 = (lk < 3 ? 1 : 3) * 64, zr2 = (lk < 3 ? 2 : 3) * 64;
     if (threadIdx.x < 128) strips[threadIdx.x / 64][3][threadIdx.x % 64] = 0.0;
@@ -218,6 +200,36 @@ __global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrVie
             acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, base, 0, 0, 0);
         }
     }
+    return ok;
+}
+
+
+template <int NSTEPS>
+__global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrView v, const uint32_t h, const int final_node,
+                                                                     double* __restrict__ scal)
+{
+    __shared__ double strips[2][4][64];   // [buffer][pivot row c, 3 = zeros][column]
+    __shared__ double X[64 * kLd];
+    const int sb = v.sb;
+    const int lane = threadIdx.x % 64, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    const int lr = lane % 16, lk = lane / 16;
+    const size_t sb2 = (size_t)sb * sb;
+    const uint32_t node = final_node ? 0u : h * (2 * blockIdx.x + 1);
+    if (node >= v.m) return;
+
+    double4_t acc[4];
+    {
+        const double* src = v.D + node * sb2;
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * wave + 4 * r + lk, j = 16 * tj + lr;
+                acc[tj][r] = (i < sb && j < sb) ? src[(size_t)i * sb + j] : (i == j ? 1.0 : 0.0);   // identity padding: extra steps are harmless
+            }
+    }
+
+    const bool ok = gj_sweep<NSTEPS>(acc, strips, wave, lane);
     if (!ok && threadIdx.x == 0) scal[SC_LIN_STATUS] = 1.0;
     // symmetric to rounding; store the symmetrised inverse (coalesced, through an LDS image)
 #pragma unroll
@@ -362,6 +374,166 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
             if (row < sb && col < sb) v.D[k * sb2 + (size_t)row * sb + col] = dk[r] - dacc[r];
         }
     }
+}
+
+// ---- small dense systems: two-block elimination by ONE workgroup on the matrix cores ---------------------------------------
+// The reference's sliding windows (slam.cpp:121-129) leave a dense reduced system of at most 19 free cameras (114 unknowns).
+// S = [A B; B^T C] with A the first ten cameras: E_A = A^-1 (register-resident block Gauss-Jordan sweep, as cr_invert),
+// T = E_A B, S_C = C - B^T T (both on the f64 matrix cores, operands as zero-padded LDS images), E_C = S_C^-1 (second sweep),
+// then every solve is four 64 x 64 matrix-vector products:  y = E_A b_A,  z = b_C - B^T y,  x_C = E_C z,  x_A = y - T x_C.
+// One round of iterative refinement against the block-sparse S itself (fixed-order row gather) takes the explicit inverses'
+// rounding out of the result.  40 dependent pivot steps instead of the 19 x 3 barrier-separated phases of the blocked Cholesky
+// (dense_small_solve, which stays for 21 and 22 cameras).
+constexpr int kDense2Threads = 256;
+constexpr int kDense2Cams = 10;      // cameras of the leading block (60 rows of the 64 x 64 image)
+
+__global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrView A, const uint32_t n_blocks,
+                                                                      const uint32_t* __restrict__ blk_row,
+                                                                      const uint32_t* __restrict__ blk_col,
+                                                                      const double* __restrict__ b, double* __restrict__ x,
+                                                                      double* __restrict__ scal)
+{
+    extern __shared__ double lds[];
+    __shared__ double strips[2][4][64];
+    __shared__ double vb[2][64], vx[2][64], vr[2][64], vy[64], vz[64], vc[64];
+    double* const IA = lds;                 // A, then E_A
+    double* const IB = IA + 64 * kLd;       // B: rows of A's cameras, columns of C's
+    double* const IT = IB + 64 * kLd;       // T = E_A B
+    double* const IC = IT + 64 * kLd;       // C, then E_C = (C - B^T T)^-1
+    const int tid = threadIdx.x, lane = tid % 64, wave = __builtin_amdgcn_readfirstlane(tid / 64);
+    const int lr = lane % 16, lk = lane / 16;
+    const int nb = (int)A.n_rows, nA = nb < kDense2Cams ? nb : kDense2Cams, nC = nb - nA, sA = 6 * nA, sC = 6 * nC;
+
+    for (int e = tid; e < 4 * 64 * kLd; e += kDense2Threads) lds[e] = 0.0;
+    __syncthreads();
+    for (uint32_t e = tid; e < n_blocks * 36; e += kDense2Threads) {
+        const uint32_t blk = e / 36, t = e - blk * 36;
+        const int r = (int)t / 6, c = (int)t % 6;
+        const int ca = (int)blk_row[blk], cb = (int)blk_col[blk];   // ca <= cb
+        const double val = A.blocks[e];
+        if (cb < nA) {
+            IA[(6 * ca + r) * kLd + 6 * cb + c] = val;
+            if (ca != cb) IA[(6 * cb + c) * kLd + 6 * ca + r] = val;
+        } else if (ca >= nA) {
+            IC[(6 * (ca - nA) + r) * kLd + 6 * (cb - nA) + c] = val;
+            if (ca != cb) IC[(6 * (cb - nA) + c) * kLd + 6 * (ca - nA) + r] = val;
+        } else {
+            IB[(6 * ca + r) * kLd + 6 * (cb - nA) + c] = val;
+        }
+    }
+    if (tid < 64) {
+        if (tid >= sA) IA[tid * kLd + tid] = 1.0;   // identity padding: the extra pivot steps are harmless
+        if (tid >= sC) IC[tid * kLd + tid] = 1.0;
+        vb[0][tid] = tid < sA ? b[tid] : 0.0;
+        vb[1][tid] = tid < sC ? b[sA + tid] : 0.0;
+    }
+    __syncthreads();
+
+    double4_t acc[4];
+    auto load_acc = [&](const double* img) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[tj][r] = img[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr];
+    };
+    auto store_acc = [&](double* img) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) img[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr] = acc[tj][r];
+    };
+    load_acc(IA);
+    bool ok = gj_sweep<2 * kDense2Cams>(acc, strips, wave, lane);
+    store_acc(IA);                          // nobody reads IA between the load above and here
+    __syncthreads();
+    if (nC > 0) {
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++) {    // T = E_A B (E_A symmetric: P^T Q with P = E_A)
+            const double4_t t4 = mfma_ptq_tile(IA, IB, 16 * wave, 16 * tj, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) IT[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr] = t4[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++) {    // S_C = C - B^T T
+            const double4_t p4 = mfma_ptq_tile(IB, IT, 16 * wave, 16 * tj, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[tj][r] = IC[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr] - p4[r];
+        }
+        __syncthreads();                    // gj_sweep rewrites the strips' zero rows: everyone is past the first sweep's reads
+        ok = gj_sweep<2 * kDense2Cams>(acc, strips, wave, lane) && ok;
+        store_acc(IC);
+        __syncthreads();
+    }
+    if (!ok && tid == 0) scal[SC_LIN_STATUS] = 1.0;
+
+    // (dA, dC) = S^-1 (rA, rC) through the stored operators; four lanes per row (16 terms each, then a quad sum), fixed order
+    const int row = tid >> 2, m0 = (tid & 3) * 16;
+    auto solve = [&](const double* rA, const double* rC, double* dA, double* dC) __attribute__((always_inline)) {
+        {
+            double y = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; m++) y += IA[row * kLd + m0 + m] * rA[m0 + m];
+            y = quad_sum(y);
+            if ((tid & 3) == 0) vy[row] = y;
+        }
+        __syncthreads();
+        if (nC > 0) {
+            {
+                double z = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; m++) z += IB[(m0 + m) * kLd + row] * vy[m0 + m];
+                z = quad_sum(z);
+                if ((tid & 3) == 0) vz[row] = rC[row] - z;
+            }
+            __syncthreads();
+            {
+                double c = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; m++) c += IC[row * kLd + m0 + m] * vz[m0 + m];
+                c = quad_sum(c);
+                if ((tid & 3) == 0) vc[row] = c;
+            }
+            __syncthreads();
+            {
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; m++) a += IT[row * kLd + m0 + m] * vc[m0 + m];
+                a = quad_sum(a);
+                if ((tid & 3) == 0) { dA[row] = vy[row] - a; dC[row] = vc[row]; }
+            }
+        } else if ((tid & 3) == 0) {
+            dA[row] = vy[row];
+            dC[row] = 0.0;
+        }
+        __syncthreads();
+    };
+    solve(vb[0], vb[1], vx[0], vx[1]);
+    // refinement: r = b - S x from the block-sparse matrix (the adjacency of the PCG kernels: every block row lists its blocks)
+    if (tid < 6 * nb) {
+        const int f = tid / 6, a = tid % 6;
+        double s = b[tid];
+        for (uint32_t e = A.row_ptr[f]; e < A.row_ptr[f + 1]; e++) {
+            const double* B = A.blocks + 36 * (size_t)A.ent_blk[e];
+            const int col = (int)A.ent_col[e];
+            const double* xv = col < nA ? vx[0] + 6 * col : vx[1] + 6 * (col - nA);
+            if (A.ent_trans[e]) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s -= B[c * 6 + a] * xv[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; c++) s -= B[a * 6 + c] * xv[c];
+            }
+        }
+        if (f < nA) vr[0][tid] = s; else vr[1][tid - sA] = s;
+    }
+    if (tid < 64) {
+        if (tid >= sA) vr[0][tid] = 0.0;
+        if (tid >= sC) vr[1][tid] = 0.0;
+    }
+    __syncthreads();
+    solve(vr[0], vr[1], vb[0], vb[1]);      // the correction lands in vb (the right-hand side is no longer needed)
+    if (tid < 6 * nb) x[tid] = tid < sA ? vx[0][tid] + vb[0][tid] : vx[1][tid - sA] + vb[1][tid - sA];
 }
 
 // ---- solve phase: every step is a matrix-vector product with a stored sb x sb operator ------------------------
@@ -877,6 +1049,21 @@ void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const d
         hipLaunchKernelGGL(cr_bwd2_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, own[lev].p, own[lev].n,
                            own[lev + 1].p, xs, x, n, done_flag);
     }
+}
+
+bool dense2_fits(uint32_t n_rows) { return n_rows >= 1 && n_rows <= 2 * (uint32_t)kDense2Cams; }
+
+void launch_dense2_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, const double* b,
+                         double* x, double* scal)
+{
+    if (!A.n_rows) return;
+    const size_t lds = sizeof(double) * 4 * 64 * kLd;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense2_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dense2_solve_kernel, dim3(1), dim3(kDense2Threads), lds, s, A, n_blocks, blk_row, blk_col, b, x, scal);
 }
 
 }  // namespace soslam

@@ -45,6 +45,10 @@ size_t pcg_work_count(uint32_t n_rows);
 // ONE workgroup in LDS, one launch.  scal[SC_LIN_STATUS] = 1 on a non-positive pivot.
 constexpr int kDenseSmallRowsMax = 22;   // 132 unknowns: 132 x 133 f64 = 140 KB of the 160 KB LDS
 bool dense_small_fits(uint32_t n_rows);
+// <= 20 block rows: two-block elimination on the matrix cores by one workgroup (crsolve.hip), same interface
+bool dense2_fits(uint32_t n_rows);
+void launch_dense2_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
+                         const double* b, double* x, double* scal);
 void launch_dense_small_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
                               const double* b, double* x, double* scal);
 

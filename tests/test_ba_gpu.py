@@ -837,3 +837,32 @@ def test_schur_chunks_longer_than_the_descriptor_registers(gpu):
     np.testing.assert_allclose(small["cost"], long_["cost"], rtol=1e-11)
     np.testing.assert_allclose(small["cams"], long_["cams"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(small["pts"], long_["pts"], rtol=1e-8, atol=1e-10)
+
+
+def test_two_block_dense_solve_matches_the_blocked_cholesky(gpu):
+    """Reduced systems of at most 20 free cameras (the reference's sliding windows) are solved by dense2_solve: two-block
+    elimination with register-resident Gauss-Jordan sweeps on the matrix cores and one round of refinement (crsolve.hip).
+    The blocked Cholesky it replaces (dense_small_solve, development switch SOSLAM_NO_DENSE2) must give the same
+    trajectory on a 20-frame window (19 free cameras: both blocks in use) and on a 7-frame one (one block only)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for n_cam in (20, 7):
+        code = ("import json, sys; sys.path.insert(0, %r)\n"
+                "from stereo_orb_slam_amd import ba, synth\n"
+                "p = synth.generate_ba(None, n_cam=%d, n_pt=3000, track_mode=1, track_len=6)\n"
+                "with ba.BundleAdjustment(ba.default_options(max_iterations=8, check_termination=0)) as h:\n"
+                "    h.load(p); s = h.solve(); log = h.iteration_log(); cams, pts = h.get_state()\n"
+                "print(json.dumps({'cost': [e.cost for e in log], 'acc': [e.accepted for e in log], 'solver': s.linear_solver,\n"
+                "                  'cams': cams.ravel().tolist(), 'pts': pts.ravel().tolist()[:90]}))\n") % (root, n_cam)
+        outs = []
+        for env_extra in ({}, {"SOSLAM_NO_DENSE2": "1"}):
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        new, old = outs
+        assert new["acc"] == old["acc"] and len(new["cost"]) >= 4
+        np.testing.assert_allclose(new["cost"], old["cost"], rtol=1e-10)
+        np.testing.assert_allclose(new["cams"], old["cams"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(new["pts"], old["pts"], rtol=1e-7, atol=1e-9)
