@@ -386,6 +386,7 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
 // (dense_small_solve, which stays for 21 and 22 cameras).
 constexpr int kDense2Threads = 256;
 constexpr int kDense2Cams = 10;      // cameras of the leading block (60 rows of the 64 x 64 image)
+constexpr int kDense2Blocks = 2 * kDense2Cams * (2 * kDense2Cams + 1) / 2;   // upper blocks of a 20-camera system: 210
 
 __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrView A, const uint32_t n_blocks,
                                                                       const uint32_t* __restrict__ blk_row,
@@ -393,9 +394,10 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
                                                                       const double* __restrict__ b, double* __restrict__ x,
                                                                       double* __restrict__ scal)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double strips[2][4][64];
     __shared__ double vb[2][64], vx[2][64], vr[2][64], vy[64], vz[64], vc[64];
+    __shared__ uint16_t brc[2 * kDense2Blocks];   // block coordinates (row, column)
     double* const IA = lds;                 // A, then E_A
     double* const IB = IA + 64 * kLd;       // B: rows of A's cameras, columns of C's
     double* const IT = IB + 64 * kLd;       // T = E_A B
@@ -404,21 +406,36 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
     const int lr = lane % 16, lk = lane / 16;
     const int nb = (int)A.n_rows, nA = nb < kDense2Cams ? nb : kDense2Cams, nC = nb - nA, sA = 6 * nA, sC = 6 * nC;
 
-    for (int e = tid; e < 4 * 64 * kLd; e += kDense2Threads) lds[e] = 0.0;
+    for (int e = tid; e < 2 * 64 * kLd; e += kDense2Threads) reinterpret_cast<double2*>(lds)[e] = make_double2(0.0, 0.0);
     __syncthreads();
-    for (uint32_t e = tid; e < n_blocks * 36; e += kDense2Threads) {
-        const uint32_t blk = e / 36, t = e - blk * 36;
-        const int r = (int)t / 6, c = (int)t % 6;
-        const int ca = (int)blk_row[blk], cb = (int)blk_col[blk];   // ca <= cb
-        const double val = A.blocks[e];
-        if (cb < nA) {
-            IA[(6 * ca + r) * kLd + 6 * cb + c] = val;
-            if (ca != cb) IA[(6 * cb + c) * kLd + 6 * ca + r] = val;
-        } else if (ca >= nA) {
-            IC[(6 * (ca - nA) + r) * kLd + 6 * (cb - nA) + c] = val;
-            if (ca != cb) IC[(6 * (cb - nA) + c) * kLd + 6 * (ca - nA) + r] = val;
-        } else {
-            IB[(6 * ca + r) * kLd + 6 * (cb - nA) + c] = val;
+    // the block coordinates go to LDS first (coalesced), then the values stream in (coalesced, eight loads in flight per lane)
+    // and are scattered to the images
+    for (uint32_t i = tid; i < n_blocks; i += kDense2Threads) { brc[i] = (uint16_t)blk_row[i]; brc[kDense2Blocks + i] = (uint16_t)blk_col[i]; }
+    __syncthreads();
+    for (uint32_t e0 = 0; e0 < n_blocks * 36; e0 += 8 * kDense2Threads) {
+        double val8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t e = e0 + (uint32_t)u * kDense2Threads + (uint32_t)tid;
+            val8[u] = e < n_blocks * 36 ? A.blocks[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t e = e0 + (uint32_t)u * kDense2Threads + (uint32_t)tid;
+            if (e >= n_blocks * 36) continue;
+            const uint32_t blk = e / 36, t = e - blk * 36;
+            const int r = (int)t / 6, c = (int)t % 6;
+            const int ca = (int)brc[blk], cb = (int)brc[kDense2Blocks + blk];   // ca <= cb
+            const double val = val8[u];
+            if (cb < nA) {
+                IA[(6 * ca + r) * kLd + 6 * cb + c] = val;
+                if (ca != cb) IA[(6 * cb + c) * kLd + 6 * ca + r] = val;
+            } else if (ca >= nA) {
+                IC[(6 * (ca - nA) + r) * kLd + 6 * (cb - nA) + c] = val;
+                if (ca != cb) IC[(6 * (cb - nA) + c) * kLd + 6 * (ca - nA) + r] = val;
+            } else {
+                IB[(6 * ca + r) * kLd + 6 * (cb - nA) + c] = val;
+            }
         }
     }
     if (tid < 64) {
@@ -510,10 +527,14 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
     };
     solve(vb[0], vb[1], vx[0], vx[1]);
     // refinement: r = b - S x from the block-sparse matrix (the adjacency of the PCG kernels: every block row lists its blocks)
-    if (tid < 6 * nb) {
-        const int f = tid / 6, a = tid % 6;
-        double s = b[tid];
-        for (uint32_t e = A.row_ptr[f]; e < A.row_ptr[f + 1]; e++) {
+    {
+        // two lanes per row share its blocks (every second one each), added in a fixed order
+        const int rw = tid >> 1, half = tid & 1;
+        const bool live = rw < 6 * nb;
+        const int f = live ? rw / 6 : 0, a = rw % 6;
+        double s = 0.0;
+        if (live)
+        for (uint32_t e = A.row_ptr[f] + (uint32_t)half; e < A.row_ptr[f + 1]; e += 2) {
             const double* B = A.blocks + 36 * (size_t)A.ent_blk[e];
             const int col = (int)A.ent_col[e];
             const double* xv = col < nA ? vx[0] + 6 * col : vx[1] + 6 * (col - nA);
@@ -525,7 +546,11 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
                 for (int c = 0; c < 6; c++) s -= B[a * 6 + c] * xv[c];
             }
         }
-        if (f < nA) vr[0][tid] = s; else vr[1][tid - sA] = s;
+        s += mov_dpp_f64<kDppXor1>(s);
+        if (live && half == 0) {
+            s += b[rw];
+            if (f < nA) vr[0][rw] = s; else vr[1][rw - sA] = s;
+        }
     }
     if (tid < 64) {
         if (tid >= sA) vr[0][tid] = 0.0;
