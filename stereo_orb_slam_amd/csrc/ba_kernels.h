@@ -176,6 +176,10 @@ struct PointsStepArgs {
 };
 void launch_points_step(hipStream_t s, const PointsStepArgs& a, const Proj& P, double* pub_src, int n_pub, int clear_first, int clear_n,
                         double* host_dst, unsigned long long* host_seq, unsigned long long seq);
+// one line-search trial of a structure-only problem (candidate at step size `step`, its cost, direction . gradient, step norm
+// and |dp|_inf into scal[SC_LS_*], published) in one launch
+void launch_points_ls(hipStream_t s, const PointsStepArgs& a, const Proj& P, double step, double* pub_src, int n_pub, double* host_dst,
+                      unsigned long long* host_seq, unsigned long long seq);
 
 // ---- Ceres' line search on bounded problems (TrustRegionMinimizer::DoLineSearch; see run_lm) ----------------------------
 // trial point x+ = Plus(x, a delta): cameras x + a dc, points projected onto the box; ls_part[block][2] = {|x+ - x|^2 of the

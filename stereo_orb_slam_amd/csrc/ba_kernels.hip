@@ -1827,6 +1827,55 @@ void launch_points_step(hipStream_t s, const PointsStepArgs& a, const Proj& P, d
     hipLaunchKernelGGL(ba_points_step_kernel, dim3(1), dim3(1024), 0, s, a, P, Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
 }
 
+// One line-search trial of a structure-only problem in ONE launch (what ba_ls_candidate, ba_pose_prepare, ba_ls_eval and
+// ba_ls_sums do for the general case): candidate x+ = clamp(x + a dp) into pts_out, its cost, direction . gradient,
+// |x+ - x|^2 and |dp|_inf into scal[SC_LS_*], published.  The per-frame call of the reference's schedule needs the search in
+// most of its iterations (two trials each): eight launches per iteration become two.
+__global__ __launch_bounds__(1024) void ba_points_ls_kernel(const PointsStepArgs a, const Proj P, const double step, const Publish pb)
+{
+    __shared__ double red[16 * 4];
+    double rho = 0.0, dir = 0.0, st2 = 0.0, dmax = 0.0;
+    for (uint32_t p = threadIdx.x; p < a.n_pt; p += 1024) {
+        double x[3], e[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double x0 = a.pts[3 * (size_t)p + k];
+            e[k] = a.dp[3 * (size_t)p + k];
+            x[k] = fmin(fmax(x0 + step * e[k], a.bound_lo), a.bound_hi);   // ParameterBlock::Plus projects onto the bounds
+            a.pts_out[3 * (size_t)p + k] = x[k];
+            st2 += (x[k] - x0) * (x[k] - x0);
+            dmax = fmax(dmax, fabs(e[k]));
+        }
+        for (uint32_t q = a.pt_start[p]; q < a.pt_start[p + 1]; q++) {
+            PosePre pr;
+            pose_load(a.campre + kPoseStride * (size_t)a.q_cam[q], pr);
+            double r[4], am[12], D[9];
+            rho += residual_ad(pr, x, a.uv[a.pt_obs[q]], P, a.huber_delta, r, am, D);
+            double u[3];   // J_p dp = A R dp
+#pragma unroll
+            for (int i = 0; i < 3; i++) u[i] = pr.R[i * 3] * e[0] + pr.R[i * 3 + 1] * e[1] + pr.R[i * 3 + 2] * e[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) dir += r[i] * (am[i * 3] * u[0] + am[i * 3 + 1] * u[1] + am[i * 3 + 2] * u[2]);
+        }
+    }
+    rho = wave_sum(rho); dir = wave_sum(dir); st2 = wave_sum(st2); dmax = wave_max(dmax);
+    if (threadIdx.x % kWave == 0) { double* o = red + 4 * (threadIdx.x / kWave); o[0] = rho; o[1] = dir; o[2] = st2; o[3] = dmax; }
+    __syncthreads();
+    static_assert(SC_LS_DIR == SC_LS_COST + 1 && SC_LS_STEP2 == SC_LS_COST + 2 && SC_LS_DMAX == SC_LS_COST + 3, "line-search slots");
+    if (threadIdx.x < 4) {
+        double v = 0.0;
+        for (int w = 0; w < 16; w++) v = threadIdx.x == 3 ? fmax(v, red[4 * w + 3]) : v + red[4 * w + threadIdx.x];
+        a.scal[SC_LS_COST + threadIdx.x] = threadIdx.x == 0 ? 0.5 * v : v;
+    }
+    publish_tail(pb);
+}
+
+void launch_points_ls(hipStream_t s, const PointsStepArgs& a, const Proj& P, double step, double* pub_src, int n_pub, double* host_dst,
+                      unsigned long long* host_seq, unsigned long long seq)
+{
+    hipLaunchKernelGGL(ba_points_ls_kernel, dim3(1), dim3(1024), 0, s, a, P, step, Publish{pub_src, host_dst, host_seq, seq, n_pub, 0, 0});
+}
+
 // ---- line search trial (TrustRegionMinimizer::DoLineSearch on bounded problems; run only when the full step fails the
 // sufficient-decrease condition) ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_ls_candidate_kernel(uint32_t n_cam, uint32_t n_pt, const double* __restrict__ cams,

@@ -1191,6 +1191,17 @@ double ls_minimize(const std::vector<double>& c, double x_min, double x_max)
 int ls_evaluate(soslam_ba* h, double a)
 {
     hipStream_t s = h->stream;
+    if (points_only(h) && h->points_only_ready) {
+        // structure only: the trial in one launch (the cameras and both pose tables are the constant ones already)
+        PointsStepArgs pa{};
+        pa.n_pt = h->n_pt; pa.pt_start = h->pt_start.p; pa.pt_obs = h->pt_obs.p; pa.q_cam = h->q_cam.p; pa.uv = h->uv.p;
+        pa.campre = h->campre.p; pa.pts = h->pts[h->cur].p; pa.pts_out = h->pts[h->cur ^ 1].p; pa.dp = h->dp.p;
+        pa.huber_delta = h->opt.huber_delta; pa.bound_lo = h->opt.lower_bound; pa.bound_hi = h->opt.upper_bound; pa.scal = h->scalp();
+        const unsigned long long seq = ++h->publish_seq;
+        launch_points_ls(s, pa, h->proj, a, h->tail(), 4 + SC_COUNT, h->host_raw, h->host_seq, seq);
+        SOSLAM_HIP_CHECK(hipGetLastError());
+        return wait_host_seq(h, h->host_seq, seq);
+    }
     SOSLAM_CHECK(h->ls_tile.alloc(2 * (size_t)std::max<uint32_t>(h->n_tiles, 1)));
     SOSLAM_CHECK(h->ls_part.alloc(2 * (size_t)ls_candidate_blocks(h->n_pt)));
     launch_ls_candidate(s, h->n_cam, h->n_pt, h->cams[h->cur].p, h->pts[h->cur].p, h->dc_full.p, h->dp.p, a, h->opt.lower_bound,
