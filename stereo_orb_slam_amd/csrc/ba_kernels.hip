@@ -1730,9 +1730,9 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
 // ---- structure-only LM iteration in one launch (see PointsStepArgs) -------------------------------------------------------
 __global__ __launch_bounds__(1024) void ba_points_step_kernel(const PointsStepArgs a, const Proj P, const Publish pb)
 {
-    __shared__ double red[16 * 8];
-    __shared__ double fin[8];
-    double cost_x = 0.0, cost_c = 0.0, mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
+    __shared__ double red[16 * 10];
+    __shared__ double fin[10];
+    double cost_x = 0.0, cost_c = 0.0, mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0, dir_c = 0.0, dmax = 0.0;
     bool bad = false;
     for (uint32_t p = threadIdx.x; p < a.n_pt; p += 1024) {
         const double x[3] = {a.pts[3 * (size_t)p], a.pts[3 * (size_t)p + 1], a.pts[3 * (size_t)p + 2]};
@@ -1782,28 +1782,36 @@ __global__ __launch_bounds__(1024) void ba_points_step_kernel(const PointsStepAr
             x2 += x[k] * x[k];
             gd += g[k] * e[k];
             gm = fmax(gm, fabs(g[k]));
+            dmax = fmax(dmax, fabs(e[k]));
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) { a.C[6 * (size_t)p + k] = c[k]; a.Cinv[6 * (size_t)p + k] = ci[k]; }
-        // the candidate's cost
+        // the candidate's cost, and direction . gradient there: the first trial of the bounded problem's line search (step size
+        // 1) is this candidate, so the search starts without a launch of its own
         for (uint32_t q = q0; q < q1; q++) {
             PosePre pr;
             pose_load(a.campre + kPoseStride * (size_t)a.q_cam[q], pr);
-            cost_c += residual_cost(pr, xc, a.uv[a.pt_obs[q]], P, a.huber_delta);
+            double r[4], am[12], D[9];
+            cost_c += residual_ad(pr, xc, a.uv[a.pt_obs[q]], P, a.huber_delta, r, am, D);
+            double u[3];   // J_p dp = A R dp
+#pragma unroll
+            for (int i = 0; i < 3; i++) u[i] = pr.R[i * 3] * e[0] + pr.R[i * 3 + 1] * e[1] + pr.R[i * 3 + 2] * e[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) dir_c += r[i] * (am[i * 3] * u[0] + am[i * 3 + 1] * u[1] + am[i * 3 + 2] * u[2]);
         }
     }
     cost_x = wave_sum(cost_x); cost_c = wave_sum(cost_c); mcc = wave_sum(mcc); st2 = wave_sum(st2); x2 = wave_sum(x2);
-    gd = wave_sum(gd); gm = wave_max(gm);
+    gd = wave_sum(gd); gm = wave_max(gm); dir_c = wave_sum(dir_c); dmax = wave_max(dmax);
     const double badf = wave_max(bad ? 1.0 : 0.0);
     if (threadIdx.x % kWave == 0) {
-        double* o = red + 8 * (threadIdx.x / kWave);
-        o[0] = cost_x; o[1] = cost_c; o[2] = mcc; o[3] = st2; o[4] = x2; o[5] = gd; o[6] = gm; o[7] = badf;
+        double* o = red + 10 * (threadIdx.x / kWave);
+        o[0] = cost_x; o[1] = cost_c; o[2] = mcc; o[3] = st2; o[4] = x2; o[5] = gd; o[6] = gm; o[7] = badf; o[8] = dir_c; o[9] = dmax;
     }
     __syncthreads();
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < 10) {
         const int k = threadIdx.x;
         double v = 0.0;
-        for (int w = 0; w < 16; w++) v = k >= 6 ? fmax(v, red[8 * w + k]) : v + red[8 * w + k];
+        for (int w = 0; w < 16; w++) v = (k == 6 || k == 7 || k == 9) ? fmax(v, red[10 * w + k]) : v + red[10 * w + k];
         if (k < 2) v *= 0.5;
         fin[k] = v;
     }
@@ -1814,6 +1822,7 @@ __global__ __launch_bounds__(1024) void ba_points_step_kernel(const PointsStepAr
         sc[SC_GDOT_PTS] = fin[5]; sc[SC_GMAX_PTS] = fin[6]; sc[SC_STOP] = 0.0;
         sc[SC_MCC_CAM] = 0.0; sc[SC_STEP2_CAM] = 0.0; sc[SC_X2_CAM] = 0.0; sc[SC_GDOT_CAM] = 0.0; sc[SC_GMAX_CAM] = 0.0;
         sc[SC_LIN_ITERS] = 0.0; sc[SC_LIN_RESID] = 0.0; sc[SC_LIN_STATUS] = 0.0; sc[SC_SCHUR_STATUS] = fin[7];
+        sc[SC_LS_COST] = fin[1]; sc[SC_LS_DIR] = fin[8]; sc[SC_LS_STEP2] = fin[3]; sc[SC_LS_DMAX] = fin[9];   // the search's trial at step size 1
         const double mc = fin[2], cand = fin[1];
         const bool ok = fin[7] == 0.0 && isfinite(mc) && isfinite(cand) && mc > 0.0 && cand <= a.x_cost + 1e-4 * fin[5];
         sc[SC_GATE] = (a.gate_enabled && ok && (a.x_cost - cand) / mc > a.min_relative_decrease) ? 1.0 : 0.0;

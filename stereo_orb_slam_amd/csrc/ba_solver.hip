@@ -1243,7 +1243,18 @@ int line_search(soslam_ba* h, const StepScalars& sc, double* step_size, double* 
         out.gradient_ok = out.value_ok && std::isfinite(out.gradient);
         return SOSLAM_OK;
     };
-    SOSLAM_CHECK(evaluate(1.0, current));     // Ceres evaluates cost AND gradient at the first trial (CUBIC interpolation)
+    // Ceres evaluates cost AND gradient at the first trial (CUBIC interpolation).  The structure-only step kernel has left
+    // both in the line-search slots already (its candidate IS the trial at step size 1)
+    if (points_only(h) && h->points_only_ready) {
+        current = LsSample{};
+        current.x = 1.0;
+        current.value = h->host_scal[SC_LS_COST];
+        current.gradient = h->host_scal[SC_LS_DIR];
+        current.value_ok = std::isfinite(current.value);
+        current.gradient_ok = current.value_ok && std::isfinite(current.gradient);
+    } else {
+        SOSLAM_CHECK(evaluate(1.0, current));
+    }
     const double dmax = h->host_scal[SC_LS_DMAX];
     int iters = 0;
     bool found = true;
