@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <complex>
+#include <thread>
 #include <cstdlib>
 #include <iterator>
 #include <memory>
@@ -71,6 +72,10 @@ struct soslam_ba {
 
     // host-side permutations (internal <-> caller order)
     std::vector<uint32_t> pt_int2user, pt_user2int, obs_int2user;
+    // host scratch of build_problem that is as long as the observation list: kept with the handle, so that a second problem of
+    // the same size pays neither the allocation nor the zero fill of 40 MB of vectors (4 ms at 1 M observations)
+    std::vector<float4> hs_uv;
+    std::vector<uint32_t> hs_obs_pt, hs_obs_cam, hs_pt_obs, hs_q_pt, hs_q_cam;
     std::vector<int32_t> h_cam_free;
     std::vector<uint32_t> h_blk_row, h_blk_col;
     std::vector<std::pair<uint32_t, uint32_t>> covis;   // job-wide camera pairs (multi-GPU)
@@ -219,6 +224,29 @@ void collect_stage_times(soslam_ba* h, soslam_ba_summary* s)
         }                                                                                        \
     } while (0)
 
+// Host threads for the memory-bound passes of build_problem: [0, n) in contiguous ranges, one per thread, when the pass is
+// large enough to pay for starting them (the reference's windows never are; a 1 M-observation problem is).  Every range
+// writes its own part of the output arrays, so the result does not depend on the number of threads.
+unsigned parallel_threads(size_t n, size_t work)
+{
+    const unsigned nt = work < 200000 ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    return n < nt ? 1u : nt;
+}
+
+template <class F>
+void parallel_ranges(size_t n, size_t work, F&& f)
+{
+    const unsigned nt = parallel_threads(n, work);
+    if (nt <= 1) { f((size_t)0, n, 0u); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
+        if (lo < hi) th.emplace_back([&f, lo, hi, t] { f(lo, hi, t); });
+    }
+    for (auto& x : th) x.join();
+}
+
 int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, const uint32_t* ocam,
                   const uint32_t* opt_, const float* ouv, const uint8_t* fixed)
 {
@@ -287,8 +315,16 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     // input is already in (camera, internal point, caller index) order.  One linear check instead of two counting sorts
     // over the observations; the order itself, and every bit of the results, are those of the sort.
     bool presorted = true;
-    for (uint32_t k = 1; k < n_obs && presorted; k++)
-        presorted = ocam[k] > ocam[k - 1] || (ocam[k] == ocam[k - 1] && h->pt_user2int[opt_[k]] >= h->pt_user2int[opt_[k - 1]]);
+    {
+        uint8_t bad[16] = {0};
+        parallel_ranges(n_obs, n_obs, [&](size_t lo, size_t hi, unsigned t) {
+            bool ok = true;
+            for (size_t k = std::max<size_t>(lo, 1); k < hi && ok; k++)
+                ok = ocam[k] > ocam[k - 1] || (ocam[k] == ocam[k - 1] && h->pt_user2int[opt_[k]] >= h->pt_user2int[opt_[k - 1]]);
+            if (!ok) bad[t] = 1;
+        });
+        for (uint8_t b1 : bad) presorted = presorted && !b1;
+    }
     if (presorted) {
         std::iota(h->obs_int2user.begin(), h->obs_int2user.end(), 0u);
     } else {
@@ -302,15 +338,25 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         for (uint32_t c = 0; c < n_cam; c++) cnt[c + 1] += cnt[c];
         for (uint32_t i = 0; i < n_obs; i++) h->obs_int2user[cnt[ocam[tmp[i]]]++] = tmp[i];
     }
-    std::vector<float4> uv(n_obs);
-    std::vector<uint32_t> v_obs_pt(n_obs), v_obs_cam(n_obs);
+    std::vector<float4>& uv = h->hs_uv;
+    std::vector<uint32_t>&v_obs_pt = h->hs_obs_pt, &v_obs_cam = h->hs_obs_cam;
+    uv.resize(n_obs); v_obs_pt.resize(n_obs); v_obs_cam.resize(n_obs);   // every element is written below
     std::vector<uint32_t> cam_start(n_cam + 1, 0);
-    for (uint32_t i = 0; i < n_obs; i++) {
-        const uint32_t k = h->obs_int2user[i];
-        uv[i] = make_float4(ouv[4 * (size_t)k], ouv[4 * (size_t)k + 1], ouv[4 * (size_t)k + 2], ouv[4 * (size_t)k + 3]);
-        v_obs_pt[i] = h->pt_user2int[opt_[k]];
-        v_obs_cam[i] = ocam[k];
-        cam_start[ocam[k] + 1]++;
+    {
+        std::vector<std::vector<uint32_t>> hist(16);
+        parallel_ranges(n_obs, n_obs, [&](size_t lo, size_t hi, unsigned t) {
+            std::vector<uint32_t>& hc = hist[t];
+            hc.assign(n_cam + 1, 0);
+            for (size_t i = lo; i < hi; i++) {
+                const uint32_t k = h->obs_int2user[i];
+                uv[i] = make_float4(ouv[4 * (size_t)k], ouv[4 * (size_t)k + 1], ouv[4 * (size_t)k + 2], ouv[4 * (size_t)k + 3]);
+                v_obs_pt[i] = h->pt_user2int[opt_[k]];
+                v_obs_cam[i] = ocam[k];
+                hc[ocam[k] + 1]++;
+            }
+        });
+        for (const auto& hc : hist)
+            for (size_t c = 0; c < hc.size(); c++) cam_start[c] += hc[c];
     }
     for (uint32_t c = 0; c < n_cam; c++) cam_start[c + 1] += cam_start[c];
 
@@ -336,10 +382,14 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     h->n_tiles = (uint32_t)tiles.size();
 
     // point-major lists (camera ascending inside a point because the scan is camera-major)
-    std::vector<uint32_t> pt_start(n_pt + 1, 0), pt_obs(n_obs), q_pt(n_obs), q_cam(n_obs);
+    std::vector<uint32_t> pt_start(n_pt + 1, 0);
+    std::vector<uint32_t>&pt_obs = h->hs_pt_obs, &q_pt = h->hs_q_pt, &q_cam = h->hs_q_cam;
+    pt_obs.resize(n_obs); q_pt.resize(n_obs); q_cam.resize(n_obs);        // every element is written below
     for (uint32_t i = 0; i < n_obs; i++) pt_start[v_obs_pt[i] + 1]++;
     for (uint32_t p = 0; p < n_pt; p++) pt_start[p + 1] += pt_start[p];
     {
+        // (a thread-parallel form of this counting sort - per-thread counts of 100 k points, then scatter - was measured at
+        // 1 M observations: 6.9 ms against 3.1 ms sequential; the counts do not fit the cores' caches)
         std::vector<uint32_t> fill(pt_start.begin(), pt_start.end() - 1);
         for (uint32_t i = 0; i < n_obs; i++) {
             const uint32_t q = fill[v_obs_pt[i]]++;
@@ -459,6 +509,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     std::vector<std::vector<uint32_t>> blk_contrib(h->n_blocks), cam_contrib(nf);
     uint64_t slab_count = 0;
     std::vector<uint8_t> q_slot(n_obs, 255);
+    std::vector<uint32_t> chunk_p_range, chunk_local;       // [chunk][2] point range, [chunk][K] free index of each window slot
     {
         std::vector<uint32_t> local, merged, fc;
         uint32_t chunk_p0 = 0;
@@ -479,35 +530,11 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                 bp = be;
             }
             ch.batch_end = (uint32_t)batches.size();
-            // window slot of every observation: a point's observations are camera-ascending and so is `local` - one
-            // merge walk per point instead of a binary search per observation
-            for (uint32_t pp = chunk_p0; pp < p_end; pp++) {
-                size_t sl = 0;
-                for (uint32_t q = pt_start[pp]; q < pt_start[pp + 1]; q++) {
-                    const int32_t f = h->h_cam_free[q_cam[q]];
-                    if (f < 0) continue;
-                    while (local[sl] < (uint32_t)f) sl++;
-                    q_slot[q] = (uint8_t)sl;
-                }
-            }
-            if (K <= 10) {
-                // the ten-camera kernel's table: the compact row of every (point, window slot) pair of every batch
-                pair_row.resize(batches.size() * (size_t)kS10PairsPerBatch, 0xFFFFFFFFu);
-                const uint32_t KL = (uint32_t)local.size();
-                for (uint32_t b = ch.batch_begin; b < ch.batch_end; b++) {
-                    const SchurBatch& bt = batches[b];
-                    for (uint32_t pp = bt.p_begin; pp < bt.p_end; pp++)
-                        for (uint32_t q = pt_start[pp]; q < pt_start[pp + 1]; q++)
-                            if (q_slot[q] != 255) pair_row[(size_t)b * kS10PairsPerBatch + (pp - bt.p_begin) * KL + q_slot[q]] = pt_obs[q];
-                }
-            }
-            for (uint32_t b = ch.batch_begin; b < ch.batch_end; b++) {
-                SchurBatch& bt = batches[b];
-                bool full = bt.p_end - bt.p_begin == (uint32_t)schur_batch_points(K) &&
-                            bt.q_end - bt.q_begin == (bt.p_end - bt.p_begin) * (uint32_t)local.size();
-                for (uint32_t q = bt.q_begin; full && q < bt.q_end; q++) full = q_slot[q] != 255;
-                bt.full = full ? 1u : 0u;
-            }
+            // the per-observation part (window slots, the ten-camera kernel's pair table, the batches' "full" flags) is done
+            // for all chunks together after this loop, chunk-parallel: it only needs the chunk's point range and cameras
+            chunk_p_range.push_back(chunk_p0);
+            chunk_p_range.push_back(p_end);
+            for (int a = 0; a < K; a++) chunk_local.push_back(a < (int)local.size() ? local[a] : UINT32_MAX);
             // slab layout of this chunk: [pair (a <= b < n_local)][36] then [camera a][6]; every pair whose block
             // exists in the pattern (it always does: the pattern is a superset) feeds that block's list
             const uint32_t base = (uint32_t)slab_count;
@@ -545,6 +572,37 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         }
         close_chunk(n_short);
     }
+    if (K <= 10) pair_row.assign(batches.size() * (size_t)kS10PairsPerBatch, 0xFFFFFFFFu);
+    parallel_ranges(chunks.size(), n_obs, [&](size_t c_lo, size_t c_hi, unsigned) {
+        for (size_t ci = c_lo; ci < c_hi; ci++) {
+            const SchurChunk& ch = chunks[ci];
+            const uint32_t* local = chunk_local.data() + ci * (size_t)K;
+            const uint32_t KL = ch.n_local;
+            // window slot of every observation: a point's observations are camera-ascending and so is `local` - one
+            // merge walk per point instead of a binary search per observation
+            for (uint32_t pp = chunk_p_range[2 * ci]; pp < chunk_p_range[2 * ci + 1]; pp++) {
+                size_t sl = 0;
+                for (uint32_t q = pt_start[pp]; q < pt_start[pp + 1]; q++) {
+                    const int32_t f = h->h_cam_free[q_cam[q]];
+                    if (f < 0) continue;
+                    while (local[sl] < (uint32_t)f) sl++;
+                    q_slot[q] = (uint8_t)sl;
+                }
+            }
+            for (uint32_t b = ch.batch_begin; b < ch.batch_end; b++) {
+                SchurBatch& bt = batches[b];
+                if (K <= 10) {
+                    // the ten-camera kernel's table: the compact row of every (point, window slot) pair of the batch
+                    for (uint32_t pp = bt.p_begin; pp < bt.p_end; pp++)
+                        for (uint32_t q = pt_start[pp]; q < pt_start[pp + 1]; q++)
+                            if (q_slot[q] != 255) pair_row[(size_t)b * kS10PairsPerBatch + (pp - bt.p_begin) * KL + q_slot[q]] = pt_obs[q];
+                }
+                bool full = bt.p_end - bt.p_begin == (uint32_t)schur_batch_points(K) && bt.q_end - bt.q_begin == (bt.p_end - bt.p_begin) * KL;
+                for (uint32_t q = bt.q_begin; full && q < bt.q_end; q++) full = q_slot[q] != 255;
+                bt.full = full ? 1u : 0u;
+            }
+        }
+    });
     // long-track points: one slab slot per camera pair and per camera, through the same contribution lists
     std::vector<LongPoint> long_pts;
     std::vector<uint32_t> lo_row, lo_cam, lo_cam_off, pair_a, pair_b, pair_off;
