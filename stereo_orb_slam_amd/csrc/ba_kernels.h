@@ -127,10 +127,6 @@ void launch_gate_publish(hipStream_t s, double* scal, double x_cost, double min_
                          int armijo_in_gate = 1);
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 
-void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
-                       const double* tile_part /* sums without the camera constant M */, const double* campre, double* B /* [F][36] */,
-                       double* gc /* [F][6] */, const double* gate = nullptr);
-
 void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
                          const double* ar, const double* campre, double* C, double* gp, const double* gate = nullptr);
 
@@ -212,7 +208,9 @@ void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts
 void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, const uint32_t* blk_ptr, const uint32_t* blk_off,
                          const uint32_t* cam_ptr, const uint32_t* cam_off, const uint32_t* blk_row, const uint32_t* blk_col,
                          const uint32_t* free_cam /* camera of each free index */, const double* campre, const double* slab,
-                         const double* B, const double* gc, double* S, double* rhs, double* diagB, double* gc_red,
+                         const uint32_t* cam_tile_start, const double* tile_part /* ba_linearize's per-tile camera sums: the kernel
+                         forms each camera's own block B and gradient g_c from them (T applied once per camera) */,
+                         double* S, double* rhs, double* diagB, double* gc_red,
                          const double* cost_in, double* cost_out /* cost_out = cost_in: this rank's cost joins the reduce payload */);
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,

@@ -412,22 +412,16 @@ __global__ __launch_bounds__(64) void ba_gate_publish_kernel(double* __restrict_
     publish_tail(pb);
 }
 
-// K3  camera blocks from the tile partials: one 64-lane workgroup per camera, lanes 0..26 each own one value and add the
-// camera's tiles in order (bitwise reproducible).  The sums arrive without the camera's constant M (see ba_linearize):
-// B = T^T B~ T, g = T^T g~ with T = blockdiag(M, I) is applied here, once per camera instead of once per observation.
-__global__ __launch_bounds__(64) void ba_cam_reduce_kernel(const uint32_t* __restrict__ cam_tile_start,
-                                                           const int32_t* __restrict__ cam_free,
-                                                           const double* __restrict__ tile_part,
-                                                           const double* __restrict__ campre,
-                                                           double* __restrict__ B, double* __restrict__ gc,
-    const double* __restrict__ gate)
+// Camera block and gradient of one camera from the tile partials, by one 64-lane workgroup: lanes 0..26 each own one value
+// and add the camera's tiles in order (bitwise reproducible).  The sums arrive without the camera's constant M (see
+// ba_linearize): B = T^T B~ T, g = T^T g~ with T = blockdiag(M, I) is applied here, once per camera instead of once per
+// observation.  Out (LDS): Bc[36] (both triangles from the same expression), gc6[6].  bt / gt / Tm: LDS scratch.
+__device__ __forceinline__ void cam_block_from_tiles(const uint32_t cam, const uint32_t* __restrict__ cam_tile_start,
+                                                     const double* __restrict__ tile_part, const double* __restrict__ campre,
+                                                     double* __restrict__ bt, double* __restrict__ gt, double* __restrict__ Tm,
+                                                     double* __restrict__ Bc, double* __restrict__ gc6)
 {
-    __shared__ double bt[36], gt[6], Tm[36];
-    if (gate && *gate == 0.0) return;   // speculative launch (see ba_step_sums_kernel): the step was not accepted
-    const uint32_t cam = blockIdx.x;
-    const int32_t f = cam_free[cam];
     const int v = threadIdx.x;
-    if (f < 0) return;
     if (v < 27) {
         double s = 0.0;
         for (uint32_t t = cam_tile_start[cam]; t < cam_tile_start[cam + 1]; t++) s += tile_part[(size_t)t * kTileVals + v];
@@ -457,14 +451,15 @@ __global__ __launch_bounds__(64) void ba_cam_reduce_kernel(const uint32_t* __res
             for (int j = 0; j < 6; j++) u += bt[i * 6 + j] * Tm[j * 6 + b];
             s += Tm[i * 6 + a] * u;
         }
-        B[36 * (size_t)f + v] = s;
+        Bc[v] = s;
     } else if (v < 42) {
         const int a = v - 36;
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; i++) s += Tm[i * 6 + a] * gt[i];
-        gc[6 * (size_t)f + a] = s;
+        gc6[a] = s;
     }
+    __syncthreads();
 }
 
 // K4  per-point J_p^T J_p and J_p^T r through the point-major index; one lane per point, each
@@ -1368,18 +1363,21 @@ __global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, 
                                                              const uint32_t* __restrict__ cam_off, const uint32_t* __restrict__ blk_row,
                                                              const uint32_t* __restrict__ blk_col, const uint32_t* __restrict__ free_cam,
                                                              const double* __restrict__ campre, const double* __restrict__ slab,
-                                                             const double* __restrict__ B, const double* __restrict__ gc,
+                                                             const uint32_t* __restrict__ cam_tile_start,
+                                                             const double* __restrict__ tile_part,
                                                              double* __restrict__ S, double* __restrict__ rhs,
                                                              double* __restrict__ diagB, double* __restrict__ gc_red,
                                                              const double* __restrict__ cost_in, double* __restrict__ cost_out)
 {
     __shared__ double t0[36], t1[36];
+    __shared__ double bt[36], gt[6], Tm[36], Bc[36], gc6[6];   // the camera's own block from the linearisation's tile sums
     const uint32_t id = blockIdx.x;
     const int t = threadIdx.x;
     if (id == 0 && t == 0) *cost_out = *cost_in;   // this rank's cost joins the reduce payload (saves a 4-us copy command)
     if (id < n_blocks) {
         const uint32_t fa = blk_row[id], fb = blk_col[id];
         const int r = t / 6, c = t % 6;
+        if (fa == fb) cam_block_from_tiles(free_cam[fa], cam_tile_start, tile_part, campre, bt, gt, Tm, Bc, gc6);   // block-uniform
         if (t < 36) {
             double s = 0.0;
             for (uint32_t e = blk_ptr[id]; e < blk_ptr[id + 1]; e++) s += slab[blk_off[e] + t];
@@ -1405,11 +1403,12 @@ __global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, 
             // a same-camera block is symmetric only to rounding after the two products: its lower entries take the
             // upper ones, so every consumer that mirrors or reads either triangle sees the same bits
             const double w = (fa == fb && r > c) ? t0[c * 6 + r] : v;
-            S[36 * (size_t)id + t] = (fa == fb ? B[36 * (size_t)fa + t] : 0.0) - w;
+            S[36 * (size_t)id + t] = (fa == fb ? Bc[t] : 0.0) - w;
         }
     } else {
         const uint32_t f = id - n_blocks;
         if (f >= n_free) return;
+        cam_block_from_tiles(free_cam[f], cam_tile_start, tile_part, campre, bt, gt, Tm, Bc, gc6);
         if (t < 6) {
             double s = 0.0;
             for (uint32_t e = cam_ptr[f]; e < cam_ptr[f + 1]; e++) s += slab[cam_off[e] + t];
@@ -1419,9 +1418,9 @@ __global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, 
         if (t < 6) {
             const double* M = campre + kPoseStride * (size_t)free_cam[f] + 9;
             const double v = t < 3 ? M[t] * t0[0] + M[3 + t] * t0[1] + M[6 + t] * t0[2] : t0[t];
-            const double g = gc[6 * (size_t)f + t];
+            const double g = gc6[t];
             rhs[6 * (size_t)f + t] = v - g;
-            diagB[6 * (size_t)f + t] = B[36 * (size_t)f + t * 7];
+            diagB[6 * (size_t)f + t] = Bc[t * 7];
             gc_red[6 * (size_t)f + t] = g;
         }
     }
@@ -1674,13 +1673,6 @@ void launch_gate_publish(hipStream_t s, double* scal, double x_cost, double min_
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out)
 {
     hipLaunchKernelGGL(sum5_kernel, dim3(1), dim3(1024), 0, s, in, n, out);
-}
-
-void launch_cam_reduce(hipStream_t s, uint32_t n_cam, const uint32_t* cam_tile_start, const int32_t* cam_free,
-                       const double* tile_part, const double* campre, double* B, double* gc, const double* gate)
-{
-    if (!n_cam) return;
-    hipLaunchKernelGGL(ba_cam_reduce_kernel, dim3(n_cam), dim3(64), 0, s, cam_tile_start, cam_free, tile_part, campre, B, gc, gate);
 }
 
 void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
@@ -2060,15 +2052,16 @@ void launch_schur_long(hipStream_t s, uint32_t n_long, const LongPoint* long_pts
 
 void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, const uint32_t* blk_ptr, const uint32_t* blk_off,
                          const uint32_t* cam_ptr, const uint32_t* cam_off, const uint32_t* blk_row, const uint32_t* blk_col,
-                         const uint32_t* free_cam, const double* campre, const double* slab, const double* B, const double* gc,
-                         double* S, double* rhs, double* diagB, double* gc_red, const double* cost_in, double* cost_out)
+                         const uint32_t* free_cam, const double* campre, const double* slab, const uint32_t* cam_tile_start,
+                         const double* tile_part, double* S, double* rhs, double* diagB, double* gc_red, const double* cost_in,
+                         double* cost_out)
 {
     if (!(n_blocks + n_free)) {
         (void)hipMemcpyAsync(cost_out, cost_in, sizeof(double), hipMemcpyDeviceToDevice, s);
         return;
     }
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(n_blocks + n_free), dim3(64), 0, s, n_blocks, n_free, blk_ptr, blk_off, cam_ptr,
-                       cam_off, blk_row, blk_col, free_cam, campre, slab, B, gc, S, rhs, diagB, gc_red, cost_in, cost_out);
+                       cam_off, blk_row, blk_col, free_cam, campre, slab, cam_tile_start, tile_part, S, rhs, diagB, gc_red, cost_in, cost_out);
 }
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,

@@ -104,7 +104,7 @@ struct soslam_ba {
     DevBuf<double> cams[2], pts[2];
     int cur = 0;
     DevBuf<double> cam_part;            // [cam_update_blocks][5] partials of the camera share of the step scalars
-    DevBuf<double> campre, campre_c, ar, dcw, tile_part, cost_part, C, gp, sp, Cinv, ptfac, B, gc, sc, lc, dc_free, dc_full, dp, part;
+    DevBuf<double> campre, campre_c, ar, dcw, tile_part, cost_part, C, gp, sp, Cinv, ptfac, sc, lc, dc_free, dc_full, dp, part;
     DevBuf<double> lin_resid, lin_work, dense, band, bandT, band_dinv, cr_ws;
     DevBuf<double> reduce_own;          // library-owned reduce buffer
     double* reduce = nullptr;           // [S blocks | rhs | diagB | gc_red | tail(4)] [scalars(SC_COUNT)]
@@ -738,8 +738,6 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->sp.alloc((size_t)n_pt * 3));
     SOSLAM_CHECK(h->Cinv.alloc((size_t)n_pt * 6));
     SOSLAM_CHECK(h->ptfac.alloc((size_t)n_pt * 12));   // kPtFac doubles per point
-    SOSLAM_CHECK(h->B.alloc((size_t)nf * 36));
-    SOSLAM_CHECK(h->gc.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->sc.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->lc.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->dc_free.alloc((size_t)nf * 6));
@@ -748,7 +746,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->part.alloc((size_t)h->n_point_blocks * 5));
     SOSLAM_CHECK(h->lin_resid.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->lin_work.alloc(std::max({pcg_work_count(nf), pcg_band_work_count(nf), pcg_multi_work_count(nf)})));
-    SOSLAM_CHECK(h->B.zero(s)); SOSLAM_CHECK(h->gc.zero(s)); SOSLAM_CHECK(h->dc_free.zero(s)); SOSLAM_CHECK(h->Cinv.zero(s));
+    SOSLAM_CHECK(h->dc_free.zero(s)); SOSLAM_CHECK(h->Cinv.zero(s));
     SOSLAM_CHECK(h->lin_resid.zero(s));
     if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
         const size_t n6 = (size_t)nf * 6;
@@ -823,7 +821,6 @@ int linearize(soslam_ba* h, bool in_lm_loop = false)
         h->campre_current = false;
         launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p,
                          h->proj, h->opt.huber_delta, h->ar.p, h->tile_part.p);
-        launch_cam_reduce(s, h->n_cam, h->cam_tile_start.p, h->cam_free.p, h->tile_part.p, h->campre.p, h->B.p, h->gc.p);
         // the cost at this point: known on the host after an accepted step (it was the candidate's cost, summed over
         // ranks); summed from the tiles only for a state the loop has not evaluated yet
         if (!h->x_cost_known) launch_sum_strided(s, h->tile_part.p, h->n_tiles, kTileVals, 27, 0.5, h->scalp() + SC_COST_X);
@@ -966,7 +963,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
         run_schur(h, lm);
         launch_schur_reduce(s, h->n_blocks, h->n_free, h->blk_contrib_ptr.p, h->blk_contrib_off.p, h->cam_contrib_ptr.p,
-                            h->cam_contrib_off.p, h->blk_row.p, h->blk_col.p, h->free_cam.p, h->campre.p, h->slab.p, h->B.p, h->gc.p,
+                            h->cam_contrib_off.p, h->blk_row.p, h->blk_col.p, h->free_cam.p, h->campre.p, h->slab.p, h->cam_tile_start.p, h->tile_part.p,
                             h->S(), h->rhs(), h->diagB(), h->gc_red(), h->scalp() + SC_COST_X, h->tail());
     }
     {
@@ -1079,7 +1076,6 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
             StageScope sc(h, SOSLAM_STAGE_LINEARIZE);
             launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->cam_free.p, h->proj,
                              h->opt.huber_delta, h->ar.p, h->tile_part.p, gate);
-            launch_cam_reduce(s, h->n_cam, h->cam_tile_start.p, h->cam_free.p, h->tile_part.p, h->campre_c.p, h->B.p, h->gc.p, gate);
         }
         if (!points_fused(h)) {
             StageScope sc(h, SOSLAM_STAGE_POINT_REDUCE);
