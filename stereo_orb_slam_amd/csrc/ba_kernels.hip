@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
             if (!fixed) {
                 // J_c = A [D | I], D = -E M with E = [vv]x and M the camera's constant:  D^T G D = M^T (E G E^T) M,
                 // D^T G = M^T (E G), D^T h = M^T (E h).  The tile sums hold the parts WITHOUT M - E G E^T, E G, G, E h, h,
-                // in the places of the 6x6 upper triangle and the gradient - and ba_cam_reduce applies M once per camera.
+                // in the places of the 6x6 upper triangle and the gradient - and ba_schur_reduce applies M once per camera.
                 const double Gf[9] = {G[0], G[1], G[2], G[1], G[3], G[4], G[2], G[4], G[5]};
                 double Z[9];   // E G: column c = vv x G[:, c]
 #pragma unroll
