@@ -983,7 +983,8 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
         const double* resid = nullptr;
         if (h->n_free) {
             if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
-                if (dense2_fits(h->n_free) && !std::getenv("SOSLAM_NO_DENSE2")) {
+                static const bool no_dense2 = std::getenv("SOSLAM_NO_DENSE2") != nullptr;   // development / tests: the blocked Cholesky
+                if (dense2_fits(h->n_free) && !no_dense2) {
                     launch_dense2_solve(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->rhs(), h->dc_free.p, h->scalp());
                 } else if (dense_small_fits(h->n_free)) {
                     launch_dense_small_solve(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->rhs(), h->dc_free.p, h->scalp());

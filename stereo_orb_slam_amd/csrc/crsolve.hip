@@ -1024,8 +1024,8 @@ void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int b
     const size_t lds_r = sizeof(double) * 4 * kImgRows * kLd;
     if (lds_r > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
     const uint32_t nt = ((uint32_t)v.sb + 15) / 16;
-    const char* stg = std::getenv("SOSLAM_CR_STAGGER");      // test hook, see cr_reduce_kernel; at most 1 ms
-    const uint32_t stagger = stg ? (uint32_t)std::min<long>(std::max<long>(std::atol(stg), 0), 100000) : 0u;
+    static const char* const stg = std::getenv("SOSLAM_CR_STAGGER");      // test hook, see cr_reduce_kernel; at most 1 ms (read once)
+    static const uint32_t stagger = stg ? (uint32_t)std::min<long>(std::max<long>(std::atol(stg), 0), 100000) : 0u;
     const double* fin = v.F;     // the gather's couplings; each level reads one coupling array and writes the other
     double* fout = v.F2;
     for (uint32_t h = 1; h < v.m; h *= 2) {
