@@ -284,7 +284,7 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, double* __restri
 __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrView v, const uint32_t h, const double* __restrict__ Fin,
                                                                      double* __restrict__ Fout, const uint32_t stagger_10ns)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     // Development hook (SOSLAM_CR_STAGGER): the first column tile of
     // every node starts late by the given time, as it may on a busy or shared device, so that any dependence of one
     // workgroup of this launch on the loads of another shows every time instead of once in a while.  Bounded wait.
@@ -324,7 +324,10 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
         const int row = w0 + 4 * r + lane / 16, col = q0 + lane % 16;
         dk[r] = (active && row < sb && col < sb) ? v.D[k * sb2 + (size_t)row * sb + col] : 0.0;
     }
-    for (int e = tid; e < 4 * kp * kLd; e += kCrReduceThreads) lds[e] = 0.0;
+    // 16-byte stores (zeroing only the padding - a quarter of the images - was measured slower: its index arithmetic costs more
+    // than the stores it saves)
+    static_assert((4 * kImgRows * kLd) % 2 == 0, "16-byte zero fill");
+    for (int e = tid; e < 2 * kp * kLd; e += kCrReduceThreads) reinterpret_cast<double2*>(lds)[e] = make_double2(0.0, 0.0);
     __syncthreads();
 
     // tile (rows i0.., cols j0..) of the accumulator to global row-major (+ optionally transposed) and to an LDS image
