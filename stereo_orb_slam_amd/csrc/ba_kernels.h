@@ -89,6 +89,17 @@ struct CamDamp {
     uint32_t n_free;
 };
 
+// The cyclic-reduction gather for a factor that is to serve a LATER solve as its preconditioner: S carries the damping lc
+// of the current radius, the factor is made for the radius in lm (the one the next iteration is expected to use); the
+// difference goes onto the diagonal of the gathered super-blocks only.
+struct CrShift {
+    const double* diagB;   // nullptr: no shift
+    const double* sc;
+    const double* lc;
+    LmDiag lm;
+    uint32_t n_free;
+};
+
 // campre[n_cam][kPoseStride]: per-camera rotation block consumed by launch_linearize / launch_cost
 void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, double* campre);
 

@@ -67,6 +67,7 @@ struct soslam_ba {
     bool pcg_band = false;              // PCG preconditioned by the band factor
     bool use_cr = false;                // band factor by block cyclic reduction (bw <= kCrBandMax)
     int cr_rounds = 1;                  // PCG rounds enqueued per solve with the exact band factor (see take_step)
+    bool cr_factor_valid = false;       // cr_ws holds a factor of an earlier iteration's reduced matrix
     int solver = SOSLAM_SOLVER_PCG;
     double setup_seconds = 0.0;
 
@@ -755,6 +756,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         h->dense.release();
     }
     h->cr_rounds = 1;
+    h->cr_factor_valid = false;
     h->use_cr = (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) && h->bw >= 1 && h->bw <= kCrBandMax && nf > 0 &&
                 std::getenv("SOSLAM_NO_CR") == nullptr;
     if (h->use_cr) {
@@ -993,12 +995,26 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                     launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
                 }
             } else if (h->use_cr && h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
-                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp);
-                launch_cr_solve(s, h->n_free, h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, nullptr);
+                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp, nullptr, h->rhs());
+                launch_cr_solve(s, h->n_free, h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, nullptr, true);
             } else if (h->use_cr && h->pcg_band) {
-                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp);
+                static const char* const lag_env = std::getenv("SOSLAM_CR_LAG");           // EXPERIMENT: one-iteration-old factor
+                static const double lag_pred = std::getenv("SOSLAM_CR_LAG_PRED") ? std::atof(std::getenv("SOSLAM_CR_LAG_PRED")) : 3.0;
+                static const int lag_rounds = std::getenv("SOSLAM_CR_LAG_ROUNDS") ? std::atoi(std::getenv("SOSLAM_CR_LAG_ROUNDS")) : 8;
+                if (lag_env && lag_env[0] == '1') {
+                    launch_cam_damp(s, h->n_free, h->diagB(), h->sc.p, damp.init_scale, h->opt.jacobi_scaling, lm, h->diag_block.p, h->S(), h->lc.p);
+                    const LmDiag lmf = lm_diag(h, std::min(h->opt.max_radius, radius * lag_pred));
+                    const CrShift shift{h->diagB(), h->sc.p, h->lc.p, lmf, h->n_free};
+                    if (!h->cr_factor_valid) launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), nullptr, nullptr);
+                    launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
+                                  h->opt.pcg_tolerance, h->cr_factor_valid ? lag_rounds : 2, h->scalp());
+                    launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), nullptr, &shift);
+                    h->cr_factor_valid = true;
+                } else {
+                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp, nullptr, h->rhs());
                 launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
-                              h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, h->cr_rounds), h->scalp());
+                              h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, h->cr_rounds), h->scalp(), true);
+                }
                 resid = h->lin_resid.p;
             } else if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
                 launch_bsr_to_band(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->bw, h->band.p);

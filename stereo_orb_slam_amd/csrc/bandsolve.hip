@@ -634,7 +634,7 @@ void launch_pcg_band(hipStream_t s, const BsrView& A, int bw, const double* band
 }
 
 void launch_pcg_cr(hipStream_t s, const BsrView& A, int bw, double* cr_ws, const double* b, double* x, double* resid, double* work,
-                   double tol, int max_rounds, double* scal)
+                   double tol, int max_rounds, double* scal, bool forward_done)
 {
     if (!A.n_rows || max_rounds < 1) return;
     const uint32_t n = A.n_rows * 6, n_wg = pcg_band_matvec_blocks(n);
@@ -644,7 +644,7 @@ void launch_pcg_cr(hipStream_t s, const BsrView& A, int bw, double* cr_ws, const
     double* state = work + 3 * (size_t)n;
     double* part = state + PS_COUNT;
     // round 0 (x0 = 0, r = b, p = z): three steps, none of which looks at the state of the previous solve
-    launch_cr_solve(s, A.n_rows, bw, cr_ws, b, z, nullptr);
+    launch_cr_solve(s, A.n_rows, bw, cr_ws, b, z, nullptr, forward_done);   // the factorisation may have carried b down the tree
     hipLaunchKernelGGL(pcg_band_matvec_kernel, dim3(n_wg), dim3(256), 0, s, A, z, q, part, nullptr);
     hipLaunchKernelGGL(pcg_first_update_kernel, dim3(1), dim3(1024), 0, s, n, n_wg, part, b, z, q, x, resid, p, state, tol, scal);
     for (int round = 1; round < max_rounds; round++) {

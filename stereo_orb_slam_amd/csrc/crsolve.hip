@@ -67,7 +67,7 @@ struct CrView {
 // (cr_build_map): every element of both arrays is written - a 6x6 block of S, its transpose, zero, or the unit
 // diagonal of a padding camera - so no memset precedes it.  blockIdx = (super-block, 0: D / 1: F).
 __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blocks, const int32_t* __restrict__ map, const CrView v,
-                                                        const CamDamp damp)
+                                                        const CamDamp damp, const CrShift shift)
 {
     const int sb = v.sb, bw = v.bw;
     const uint32_t i = blockIdx.x;
@@ -96,6 +96,13 @@ __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blo
     // lane = column, wave = every fourth row: divisions by the constant 6 only, coalesced stores, independent loads
     const int c = threadIdx.x % 64, lb = c / 6, cc = c - lb * 6;
     if (c >= sb) return;
+    // a factor made for ANOTHER damping than the one S carries (lagged preconditioner, see CrShift): the difference goes
+    // onto D's diagonal, S itself is left alone
+    double extra = 0.0;
+    if (shift.diagB && !is_f) {
+        const uint32_t u = i * (uint32_t)sb + (uint32_t)c;
+        if (u < shift.n_free * 6) extra = point_lambda(shift.diagB[u], shift.sc[u], shift.lm) - shift.lc[u];
+    }
 #pragma unroll 4
     for (int r = threadIdx.x / 64; r < sb; r += 4) {
         const int la = r / 6, rr = r - la * 6;
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blo
             const int32_t id = la <= lb ? mp[la * bw + lb] : mp[lb * bw + la];
             if (id >= 0) val = la <= lb ? blocks[36 * (size_t)id + rr * 6 + cc] : blocks[36 * (size_t)id + cc * 6 + rr];
             else if (id == -2 && r == c) val = 1.0;
+            if (r == c) val += extra;
         }
         dst[(size_t)r * sb + c] = val;
     }
@@ -130,74 +138,91 @@ __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blo
 constexpr int kCrInvertThreads = 256;
 
 // The sweep proper: the 64 x 64 image in the accumulator registers of four waves (wave w: tile row w), in place.  strips:
-// [buffer 2][pivot row c, 3 = zeros][column 64] in LDS.  Returns false when a pivot block was not positive definite.
+// [buffer 2][pivot row c, 3 = zeros][column 64] in LDS; pblk: [buffer 2][9 of 16] the pivot block itself.  Returns false when
+// a pivot block was not positive definite.
+//
+// A step is bound by the number of vector instructions a wave issues between two exchanges (an f64 vector instruction costs
+// a single wave about eight cycles), so the step is arranged to need few of them:
+//   * the pivot rows are published with the IDENTITY in the pivot columns (the pivot block itself goes to pblk), and the
+//     accumulators are zeroed on pivot rows (by their owner, while it publishes them) and pivot columns.  Then one formula
+//     covers every position:  new = base + A' B,  B[k][j] = strip[k][j] (no arithmetic),  A'[i][k] = -s_i sum_c strip[c][i]
+//     Pinv[c][k]  with s_i = -1 for rows up to and including the pivot rows, +1 below (three multiply-adds per lane and
+//     step): pivot rows become Pinv a, pivot columns -A_iK Pinv, the pivot block Pinv, the rest A_ij - A_iK Pinv A_Kj;
+//   * lane group lk needs row lk of Pinv only.  It reads the pivot block through the cyclic permutation that puts row lk
+//     first and evaluates ONE row of the adjugate (three cofactors instead of six, no selects); the determinant is taken
+//     from lane 0 for everybody.  A symmetric pair of entries comes out of the same two products rounded the same way in
+//     both groups, so the inverse is bitwise symmetric - the sweep relies on it (rows taken from differently rounded
+//     inverses were measured to cost four digits of the factor).
 template <int NSTEPS>
-__device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4][64], const int wave, const int lane)
+__device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4][64], double (*pblk)[16], const int wave, const int lane)
 {
     const int lr = lane % 16, lk = lane / 16;
-    // Lane group lk = l/16 feeds k = lk of both operands; group 3 (the padding k = 3) reads a strip row of zeros.
-    const int zr0 = (lk < 3 ? 0 : 3) * 64, zr1 = (lk < 3 ? 1 : 3) * 64, zr2 = (lk < 3 ? 2 : 3) * 64;
+    const int g = lk < 3 ? lk : 0;                       // the padding group computes group 0's row and multiplies zeros with it
+    const int p0 = g, p1 = (g + 1) % 3, p2 = (g + 2) % 3;
+    // strip rows this lane reads: its operand row (zeros for the padding k = 3) and the three pivot rows in permuted order
+    const int zb = (lk < 3 ? lk : 3) * 64;
+    const int za0 = (lk < 3 ? p0 : 3) * 64, za1 = (lk < 3 ? p1 : 3) * 64, za2 = (lk < 3 ? p2 : 3) * 64;
+    // the pivot block is read from its upper triangle only (the accumulators are symmetric up to rounding; every group must
+    // see the same numbers)
+    const int u01 = (p0 < p1 ? p0 : p1) * 3 + (p0 < p1 ? p1 : p0), u02 = (p0 < p2 ? p0 : p2) * 3 + (p0 < p2 ? p2 : p0),
+              u12 = (p1 < p2 ? p1 : p2) * 3 + (p1 < p2 ? p2 : p1);
+    const int i_row = 16 * wave + lr;                    // the row this lane feeds to the A operand
     if (threadIdx.x < 128) strips[threadIdx.x / 64][3][threadIdx.x % 64] = 0.0;
     bool ok = true;
 #pragma unroll
     for (int kb = 0; kb < NSTEPS; kb++) {   // straight-line code: every register index below is static
         const int k0 = 3 * kb;
         double* strip = &strips[kb & 1][0][0];
+        double* pb = &pblk[kb & 1][0];
         // pivot rows -> LDS (row k0 + c lives in wave (k0+c)/16, accumulator register ((k0+c)%16)/4, lane group (k0+c)%4)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int row = k0 + c;
             if (wave == row / 16 && lk == row % 4) {
 #pragma unroll
-                for (int tj = 0; tj < 4; tj++) strip[c * 64 + 16 * tj + lr] = acc[tj][(row % 16) / 4];
+                for (int tj = 0; tj < 4; tj++) {
+                    const int j = 16 * tj + lr;
+                    double val = acc[tj][(row % 16) / 4];
+                    const bool tile_has_pcol = k0 + 2 >= 16 * tj && k0 < 16 * tj + 16;   // static
+                    if (tile_has_pcol) {
+                        const int cj = j - k0;
+                        if (cj >= 0 && cj < 3) {
+                            pb[c * 3 + cj] = val;
+                            val = cj == c ? 1.0 : 0.0;
+                        }
+                    }
+                    strip[c * 64 + j] = val;
+                    acc[tj][(row % 16) / 4] = 0.0;
+                }
             }
         }
         __syncthreads();
-        // Every lane inverts the same block with the same operations: P^-1 must be the SAME symmetric matrix in all
-        // lane groups (rows taken from differently rounded inverses make the sweep inconsistent - measured: four
-        // digits of the factor lost).  r0 r1 r2 = row lk of P^-1.
-        const double m[6] = {strip[k0], strip[k0 + 1], strip[k0 + 2], strip[64 + k0 + 1], strip[64 + k0 + 2], strip[128 + k0 + 2]};
-        // every strip value this step needs is requested here, in front of the inverse's dependent chain (the compiler
-        // otherwise places the operand reads behind it: three more LDS round trips on the critical path of the step)
-        double sv[4][3];
+        // requests first, arithmetic behind them
+        const double a = pb[p0 * 4], b = pb[u01], c = pb[u02], d = pb[p1 * 4], e = pb[u12], f = pb[p2 * 4];
+        const double ac0 = strip[za0 + i_row], ac1 = strip[za1 + i_row], ac2 = strip[za2 + i_row];
+        double sv[4];
 #pragma unroll
-        for (int tj = 0; tj < 4; tj++) {
-            const int j = 16 * tj + lr;
-            sv[tj][0] = strip[zr0 + j]; sv[tj][1] = strip[zr1 + j]; sv[tj][2] = strip[zr2 + j];
-        }
-        const double av_strip = strip[lk * 64 + 16 * wave + lr];
-        double Pi[6];
-        ok = sym3_inverse_fast(m, Pi) && ok;     // xx xy xz yy yz zz
-        const double r0 = lk == 0 ? Pi[0] : lk == 1 ? Pi[1] : Pi[2];
-        const double r1 = lk == 0 ? Pi[1] : lk == 1 ? Pi[3] : Pi[4];
-        const double r2 = lk == 0 ? Pi[2] : lk == 1 ? Pi[4] : Pi[5];
+        for (int tj = 0; tj < 4; tj++) sv[tj] = strip[zb + 16 * tj + lr];
+        // row 0 of the inverse of the permuted block = row lk of Pinv in the column order p0 p1 p2
+        const double c00 = __builtin_fma(d, f, -(e * e)), c01 = __builtin_fma(c, e, -(b * f)), c02 = __builtin_fma(b, e, -(c * d));
+        const double det_own = __builtin_fma(a, c00, __builtin_fma(b, c01, c * c02));
+        const double det = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(det_own)),
+                                            __builtin_amdgcn_readfirstlane(__double2loint(det_own)));
+        ok = ok && (a > 0.0) && (c00 > 0.0) && (det > 0.0);
+        double id = __builtin_amdgcn_rcp(det);
+        id = id * (2.0 - det * id);
+        id = id * (2.0 - det * id);
         // A'[i][k = lk], i = 16 wave + lr
-        double aop;
-        {
-            const int i = 16 * wave + lr, ci = i - k0;
-            const double av = av_strip;
-            aop = i < k0 ? av : -av;
-            if (ci >= 0 && ci < 3) aop = lk == ci ? 1.0 : 0.0;
-        }
+        double aop = (ac0 * c00 + ac1 * c01 + ac2 * c02) * id;
+        aop = i_row < k0 + 3 ? aop : -aop;
 #pragma unroll
         for (int tj = 0; tj < 4; tj++) {
-            const int j = 16 * tj + lr;
-            double bop = r0 * sv[tj][0] + r1 * sv[tj][1] + r2 * sv[tj][2];
-            double4_t base = acc[tj];
             const bool tile_has_pcol = k0 + 2 >= 16 * tj && k0 < 16 * tj + 16;   // static
             if (tile_has_pcol) {
-                const int cj = j - k0;
-                if (cj >= 0 && cj < 3) {
-                    bop = lk == 3 ? 0.0 : (cj == 0 ? r0 : cj == 1 ? r1 : r2);
-                    base = double4_t{0.0, 0.0, 0.0, 0.0};
-                }
+                const int cj = 16 * tj + lr - k0;
+                if (cj >= 0 && cj < 3) acc[tj] = double4_t{0.0, 0.0, 0.0, 0.0};
             }
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const int row = k0 + c;
-                if (wave == row / 16 && lk == row % 4) base[(row % 16) / 4] = 0.0;   // static register index
-            }
-            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, base, 0, 0, 0);
+            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, sv[tj], acc[tj], 0, 0, 0);
         }
     }
     return ok;
@@ -209,6 +234,7 @@ __global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrVie
                                                                      double* __restrict__ scal)
 {
     __shared__ double strips[2][4][64];   // [buffer][pivot row c, 3 = zeros][column]
+    __shared__ double pblk[2][16];        // [buffer][the pivot block]
     __shared__ double X[64 * kLd];
     const int sb = v.sb;
     const int lane = threadIdx.x % 64, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
@@ -229,8 +255,8 @@ __global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrVie
             }
     }
 
-    const bool ok = gj_sweep<NSTEPS>(acc, strips, wave, lane);
-    if (!ok && threadIdx.x == 0) scal[SC_LIN_STATUS] = 1.0;
+    const bool ok = gj_sweep<NSTEPS>(acc, strips, pblk, wave, lane);
+    if (!ok) scal[SC_LIN_STATUS] = 1.0;   // every lane tests its own part of the pivot blocks; all write the same word
     // symmetric to rounding; store the symmetrised inverse (coalesced, through an LDS image)
 #pragma unroll
     for (int tj = 0; tj < 4; tj++)
@@ -281,10 +307,24 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, double* __restri
 // The fill F_k <- -Q_a^T F_a goes to Fout, NOT over F_k: the column-tile workgroups of a node all read the whole of the
 // old F_k, and nothing orders one workgroup's stores against another's loads inside a launch (on a busy or shared device
 // they start at different times - a workgroup arriving late would stage rows a sibling has already replaced).
+//
+// The forward sweep of a solve rides along (fwd.w != nullptr): a right-hand side that is known when the factorisation starts
+// (the first PCG round's b) needs  w_k = src_k - Q_a^T src_a - P_c^T src_c  at this level, and the column tile q of Q_a and
+// of P_c that the sum needs lies in LDS here anyway - the workgroup adds its sixteen entries of w_k (sixteen partial sums per
+// entry, fixed order), in place: a level writes the nodes k and reads the nodes a, c, which are different nodes.  The solve
+// then starts at the top of the tree (launch_cr_solve, forward_done): two launches fewer per solve.
+struct CrFwd {
+    const double* src;   // values of the nodes a, c, k before this level: the caller's right-hand side at h = 1, w afterwards
+    uint32_t n_src;      // valid entries of src (it reads as zero beyond them)
+    double* w;           // padded work vector (m * sb); nullptr: no forward sweep
+};
+
 __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrView v, const uint32_t h, const double* __restrict__ Fin,
-                                                                     double* __restrict__ Fout, const uint32_t stagger_10ns)
+                                                                     double* __restrict__ Fout, const uint32_t stagger_10ns, const CrFwd fwd)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double fy[2][64];          // src_a, src_c
+    __shared__ double fred[2][16][16];    // partial sums of Q_a^T src_a and P_c^T src_c: [a / c][part][entry]
     // Development hook (SOSLAM_CR_STAGGER): the first column tile of
     // every node starts late by the given time, as it may on a busy or shared device, so that any dependence of one
     // workgroup of this launch on the loads of another shows every time instead of once in a while.  Bounded wait.
@@ -324,11 +364,33 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
         const int row = w0 + 4 * r + lane / 16, col = q0 + lane % 16;
         dk[r] = (active && row < sb && col < sb) ? v.D[k * sb2 + (size_t)row * sb + col] : 0.0;
     }
+    const bool do_fwd = fwd.w != nullptr;
+    double fsrc = 0.0, fk = 0.0;
+    if (do_fwd) {
+        if (tid < 128) {
+            const bool on = tid < 64 ? has_a : has_c;
+            const size_t idx = (size_t)(tid < 64 ? a : c) * sb + (size_t)(tid % 64);
+            fsrc = (on && tid % 64 < sb && idx < fwd.n_src) ? fwd.src[idx] : 0.0;
+        } else if (tid < 144) {
+            const int t = q0 + tid - 128;
+            const size_t idx = (size_t)k * sb + (size_t)t;
+            fk = (t < sb && idx < fwd.n_src) ? fwd.src[idx] : 0.0;
+        }
+    }
     // 16-byte stores (zeroing only the padding - a quarter of the images - was measured slower: its index arithmetic costs more
     // than the stores it saves)
     static_assert((4 * kImgRows * kLd) % 2 == 0, "16-byte zero fill");
     for (int e = tid; e < 2 * kp * kLd; e += kCrReduceThreads) reinterpret_cast<double2*>(lds)[e] = make_double2(0.0, 0.0);
+    if (do_fwd && tid < 128) fy[tid / 64][tid % 64] = fsrc;
     __syncthreads();
+    // sixteen lanes per entry of the column tile: part p sums the rows p, p + 16, .. of the tile in B2 against y
+    auto fwd_partial = [&](const double* img, const double* y, double (*red)[16]) {
+        const int j = tid % 16, part = tid / 16;
+        double sum = 0.0;
+#pragma unroll
+        for (int m = part; m < kp; m += 16) sum += img[m * kLd + q0 + j] * y[m];
+        red[part][j] = sum;
+    };
 
     // tile (rows i0.., cols j0..) of the accumulator to global row-major (+ optionally transposed) and to an LDS image
     auto put = [&](const double4_t acc, int i0, int j0, double* out, double* outT, double* img, double sign) {
@@ -351,6 +413,7 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
         __syncthreads();
         if (active) put(mfma_ptq_tile(B0, B1, w0, q0, lane), w0, q0, v.Q + a * sb2, v.QT + a * sb2, B2, 1.0);   // Q_a[:, q]
         __syncthreads();
+        if (do_fwd) fwd_partial(B2, fy[0], fred[0]);
         if (active) {
             dacc = mfma_ptq_tile(B1, B2, w0, q0, lane);                                   // (F_k Q_a)[w, q]
             // rows q of the fill: -(Q_a[:, q])^T F_a, this wave takes column tile w
@@ -364,6 +427,7 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
         __syncthreads();
         if (active) put(mfma_ptq_tile(B0, B1, w0, q0, lane), w0, q0, v.P + c * sb2, v.PT + c * sb2, B2, 1.0);   // P_c[:, q]
         __syncthreads();
+        if (do_fwd) fwd_partial(B2, fy[1], fred[1]);
         if (active) {
             const double4_t s = mfma_ptq_tile(B1, B2, w0, q0, lane);                      // (F_c^T P_c)[w, q]
 #pragma unroll
@@ -375,6 +439,22 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
         for (int r = 0; r < 4; r++) {
             const int row = w0 + 4 * r + lane / 16, col = q0 + lane % 16;
             if (row < sb && col < sb) v.D[k * sb2 + (size_t)row * sb + col] = dk[r] - dacc[r];
+        }
+    }
+    if (do_fwd) {
+        __syncthreads();
+        if (tid >= 128 && tid < 144) {
+            const int j = tid - 128, t = q0 + j;
+            double sa = 0.0, sc = 0.0;
+            if (has_a) {
+#pragma unroll
+                for (int p = 0; p < 16; p++) sa += fred[0][p][j];
+            }
+            if (has_c) {
+#pragma unroll
+                for (int p = 0; p < 16; p++) sc += fred[1][p][j];
+            }
+            if (t < sb) fwd.w[(size_t)k * sb + t] = fk - (sa + sc);
         }
     }
 }
@@ -399,6 +479,7 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double strips[2][4][64];
+    __shared__ double pblk[2][16];
     __shared__ double vb[2][64], vx[2][64], vr[2][64], vy[64], vz[64], vc[64];
     __shared__ uint16_t brc[2 * kDense2Blocks];   // block coordinates (row, column)
     double* const IA = lds;                 // A, then E_A
@@ -463,7 +544,7 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
             for (int r = 0; r < 4; r++) img[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr] = acc[tj][r];
     };
     load_acc(IA);
-    bool ok = gj_sweep<2 * kDense2Cams>(acc, strips, wave, lane);
+    bool ok = gj_sweep<2 * kDense2Cams>(acc, strips, pblk, wave, lane);
     store_acc(IA);                          // nobody reads IA between the load above and here
     __syncthreads();
     if (nC > 0) {
@@ -481,11 +562,11 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
             for (int r = 0; r < 4; r++) acc[tj][r] = IC[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr] - p4[r];
         }
         __syncthreads();                    // gj_sweep rewrites the strips' zero rows: everyone is past the first sweep's reads
-        ok = gj_sweep<2 * kDense2Cams>(acc, strips, wave, lane) && ok;
+        ok = gj_sweep<2 * kDense2Cams>(acc, strips, pblk, wave, lane) && ok;
         store_acc(IC);
         __syncthreads();
     }
-    if (!ok && tid == 0) scal[SC_LIN_STATUS] = 1.0;
+    if (!ok) scal[SC_LIN_STATUS] = 1.0;   // as in cr_invert: every lane tests its own part of the pivot blocks
 
     // (dA, dC) = S^-1 (rA, rC) through the stored operators; four lanes per row (16 terms each, then a quad sum), fixed order
     const int row = tid >> 2, m0 = (tid & 3) * 16;
@@ -1018,12 +1099,25 @@ void cr_build_map(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* bl
     }
 }
 
-void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp)
+// levels the forward sweep of a solve runs two at a time (cr_fwd2): 2 * pairs levels from h = 1; the rest belongs to the top kernel
+static int cr_fwd_pairs(uint32_t m)
+{
+    uint32_t h_top = 1;
+    while (2 * h_top < m) h_top *= 2;
+    int pairs = 0;
+    for (uint32_t h = 1; 2 * h < h_top; h *= 4) pairs++;
+    return pairs;
+}
+
+void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp,
+                      const CrShift* shift, const double* fwd_b)
 {
     if (!A.n_rows) return;
     const CrView v = make_view(A.n_rows, bw, ws);
     CamDamp none{};
-    hipLaunchKernelGGL(cr_gather_kernel, dim3(v.m, 2), dim3(256), 0, s, const_cast<double*>(A.blocks), map, v, damp ? *damp : none);
+    CrShift no_shift{};
+    hipLaunchKernelGGL(cr_gather_kernel, dim3(v.m, 2), dim3(256), 0, s, const_cast<double*>(A.blocks), map, v, damp ? *damp : none,
+                       shift ? *shift : no_shift);
     const size_t lds_r = sizeof(double) * 4 * kImgRows * kLd;
     if (lds_r > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
     const uint32_t nt = ((uint32_t)v.sb + 15) / 16;
@@ -1031,15 +1125,23 @@ void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int b
     static const uint32_t stagger = stg ? (uint32_t)std::min<long>(std::max<long>(std::atol(stg), 0), 100000) : 0u;
     const double* fin = v.F;     // the gather's couplings; each level reads one coupling array and writes the other
     double* fout = v.F2;
-    for (uint32_t h = 1; h < v.m; h *= 2) {
+    // the forward sweep of the solve that follows (fwd_b: its right-hand side), for the levels launch_cr_solve would run as pairs
+    const int fwd_levels = fwd_b ? 2 * cr_fwd_pairs(v.m) : 0;
+    double* W = ws + kCrMats * (size_t)v.m * v.sb * v.sb;
+    const uint32_t n = A.n_rows * 6, n_pad = v.m * (uint32_t)v.sb;
+    int lev = 0;
+    for (uint32_t h = 1; h < v.m; h *= 2, lev++) {
         launch_cr_invert(s, count_odd(v.m, h), v, h, 0, scal);
-        hipLaunchKernelGGL(cr_reduce_kernel, dim3(count_even(v.m, h), nt), dim3(kCrReduceThreads), lds_r, s, v, h, fin, fout, stagger);
+        CrFwd fwd{nullptr, 0u, nullptr};
+        if (lev < fwd_levels) fwd = CrFwd{lev == 0 ? fwd_b : W, lev == 0 ? n : n_pad, W};
+        hipLaunchKernelGGL(cr_reduce_kernel, dim3(count_even(v.m, h), nt), dim3(kCrReduceThreads), lds_r, s, v, h, fin, fout, stagger, fwd);
         double* t = const_cast<double*>(fin); fin = fout; fout = t;
     }
     launch_cr_invert(s, 1, v, 0u, 1, scal);
 }
 
-void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const double* b, double* x, const double* done_flag)
+void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const double* b, double* x, const double* done_flag,
+                     bool forward_done)
 {
     if (!n_rows) return;
     const CrView v = make_view(n_rows, bw, ws);
@@ -1060,12 +1162,22 @@ void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const d
     Src cur{b, n};
     int nb = 0, lev = 0;
     uint32_t h = 1;
-    for (; 2 * h < h_top; h *= 4, lev += 2) {
-        double* out = buf[nb]; nb ^= 1;
-        own[lev] = cur;
-        hipLaunchKernelGGL(cr_fwd2_kernel, dim3((v.m + 4 * h - 1) / (4 * h)), dim3(kCrSolveThreads), 0, s, v, h, cur.p, cur.n, out, done_flag);
-        cur = Src{out, n_pad};
-        own[lev + 1] = cur;
+    if (forward_done) {
+        // the factorisation carried these levels (launch_cr_factor, fwd_b == b): every node's value lies in buf[0], in place,
+        // except the nodes of the first level, which were only read
+        const int pairs = cr_fwd_pairs(v.m);
+        for (int l = 0; l < 2 * pairs; l++) own[l] = l == 0 ? Src{b, n} : Src{buf[0], n_pad};
+        if (pairs > 0) cur = Src{buf[0], n_pad};
+        for (int q = 0; q < pairs; q++) h *= 4;
+        lev = 2 * pairs;
+    } else {
+        for (; 2 * h < h_top; h *= 4, lev += 2) {
+            double* out = buf[nb]; nb ^= 1;
+            own[lev] = cur;
+            hipLaunchKernelGGL(cr_fwd2_kernel, dim3((v.m + 4 * h - 1) / (4 * h)), dim3(kCrSolveThreads), 0, s, v, h, cur.p, cur.n, out, done_flag);
+            cur = Src{out, n_pad};
+            own[lev + 1] = cur;
+        }
     }
     // an odd number of levels below the top leaves one: it joins the top (cr_top2)
     if (h < h_top)

@@ -89,12 +89,17 @@ size_t cr_map_count(uint32_t n_rows, int bw);   // int32 entries of the gather m
 void cr_build_map(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, int32_t* map);   // host
 // damp != NULL: the gather also applies the camera damping to S in place (instead of a launch_cam_damp before it)
 struct CamDamp;
-void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp);
+struct CrShift;   // ba_kernels.h: the factor is made for another damping than the one S carries
+// fwd_b != NULL: the factorisation also carries the forward sweep of the solve that follows for this right-hand side (the
+// levels launch_cr_solve would run as pairs); that solve must then be called with forward_done = true and the same b
+void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp,
+                      const CrShift* shift = nullptr, const double* fwd_b = nullptr);
 // x = S^-1 b with the factors in ws; every launch returns at once when *done_flag != 0 (may be NULL)
-void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const double* b, double* x, const double* done_flag);
+void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const double* b, double* x, const double* done_flag,
+                     bool forward_done = false);
 // PCG rounds as launch_pcg_band, preconditioner = the cyclic-reduction factor
 void launch_pcg_cr(hipStream_t s, const BsrView& A, int bw, double* cr_ws, const double* b, double* x, double* resid, double* work,
-                   double tol, int max_rounds, double* scal);
+                   double tol, int max_rounds, double* scal, bool forward_done = false);
 
 }  // namespace soslam
 
