@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const double* __restrict__ D
 #pragma unroll
         for (int tj = 0; tj < 4; tj++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[tj][r] = MODE < 0 ? D[(size_t)blockIdx.x * 4096 + (16 * wave + 4 * r + lk) * 64 + 16 * tj + lr] : D[(size_t)blockIdx.x * 4096 + (16 * tj + 4 * r + lk) * 64 + 16 * wave + lr];
+            for (int r = 0; r < 4; r++) acc[tj][r] = D[(size_t)blockIdx.x * 4096 + (16 * tj + 4 * r + lk) * 64 + 16 * wave + lr];   // wave w: tile column w
         __syncthreads();
         const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
         const bool ok = MODE < 0 ? gj_sweep<NSTEPS>(acc, strips, pblk, wave, lane) : gj_sweep_x<NSTEPS, (MODE < 0 ? 0 : MODE)>(acc, strips, pblk, wave, lane);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void probe_kernel(const double* __restrict__ D
 #pragma unroll
     for (int tj = 0; tj < 4; tj++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) { if (MODE < 0) E[(size_t)blockIdx.x * 4096 + (16 * wave + 4 * r + lk) * 64 + 16 * tj + lr] = acc[tj][r]; else E[(size_t)blockIdx.x * 4096 + (16 * tj + 4 * r + lk) * 64 + 16 * wave + lr] = acc[tj][r]; }
+        for (int r = 0; r < 4; r++) E[(size_t)blockIdx.x * 4096 + (16 * tj + 4 * r + lk) * 64 + 16 * wave + lr] = acc[tj][r];
     if (threadIdx.x == 0) { t[2 * blockIdx.x] = c_sum; t[2 * blockIdx.x + 1] = r_sum; }
 }
 
@@ -183,7 +183,7 @@ int main()
     double *dD, *dE; unsigned long long* dt;
     hipMalloc(&dD, h.size() * 8); hipMalloc(&dE, h.size() * 8); hipMalloc(&dt, nb * 16);
     hipMemcpy(dD, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-    for (int mode : {0, 1, 2, 3, 4, 5, 7, 8, 16, 23, 31}) {
+    for (int mode : {-1, 0}) {
         const int grid = 1;
         for (int it = 0; it < 2; it++) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -137,72 +137,105 @@ __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blo
 //     -A_iK P^-1, the pivot block P^-1, everything else A_ij - A_iK P^-1 A_Kj.
 constexpr int kCrInvertThreads = 256;
 
-// The sweep proper: the 64 x 64 image in the accumulator registers of four waves (wave w: tile row w), in place.  strips:
-// [buffer 2][pivot row c, 3 = zeros][column 64] in LDS; pblk: [buffer 2][9 of 16] the pivot block itself.  Returns false when
-// a pivot block was not positive definite.
+// The sweep proper: the 64 x 64 image in the accumulator registers of four waves, in place.  Wave w owns tile COLUMN w:
+// acc[tr][r] at lane (lk = l/16, lr = l%16) is the element (16 tr + 4 r + lk, 16 w + lr).  strips: [buffer 2][pivot row c,
+// 3 = zeros][column 64] in LDS; pblk: [buffer 2][9 of 16] the pivot block itself.  Returns false when a pivot block was not
+// positive definite.
 //
-// A step is bound by the number of vector instructions a wave issues between two exchanges (an f64 vector instruction costs
-// a single wave about eight cycles), so the step is arranged to need few of them:
+// A step is a chain: exchange of the pivot rows -> inverse of the pivot block -> operands -> matrix instruction -> the NEXT
+// pivot rows ready for their exchange, and a single wave pays every instruction of it in full (measured on gfx950, one wave
+// per SIMD: an f64 vector instruction 13 cycles whether or not it depends on the one before, v_mfma_f64_16x16x4_f64 64, its
+// result in a vector register 48 later, LDS store -> barrier -> load 156, readfirstlane round trip 60; scripts/probes/).  So
+// the step is arranged to need few instructions on that chain:
+//   * a wave owns a tile column.  Every wave then holds ONE tile of the next pivot rows: it updates that tile first, publishes
+//     its sixteen columns of the rows (one store when the three rows share an accumulator register, else two) and leaves the
+//     other three updates to the start of the next step, where they run beside that step's LDS requests.  The B operand is the
+//     same for a wave's four tiles (strip[k][16 w + lr], no arithmetic); the A operand differs per tile row (three
+//     multiply-adds each).  (One wave per tile ROW, the earlier form, made the owner of the next pivot rows wait for its four
+//     matrix instructions and then write twelve row pieces under three lane masks while the other waves sat at the barrier:
+//     1 230 cycles per step against 1 050.)
 //   * the pivot rows are published with the IDENTITY in the pivot columns (the pivot block itself goes to pblk), and the
-//     accumulators are zeroed on pivot rows (by their owner, while it publishes them) and pivot columns.  Then one formula
-//     covers every position:  new = base + A' B,  B[k][j] = strip[k][j] (no arithmetic),  A'[i][k] = -s_i sum_c strip[c][i]
-//     Pinv[c][k]  with s_i = -1 for rows up to and including the pivot rows, +1 below (three multiply-adds per lane and
-//     step): pivot rows become Pinv a, pivot columns -A_iK Pinv, the pivot block Pinv, the rest A_ij - A_iK Pinv A_Kj;
+//     accumulators are zeroed on pivot rows (by the lanes that publish them) and pivot columns.  Then one formula covers
+//     every position:  new = base + A' B,  A'[i][k] = -s_i sum_c strip[c][i] Pinv[c][k]  with s_i = -1 for rows up to and
+//     including the pivot rows, +1 below: pivot rows become Pinv a, pivot columns -A_iK Pinv, the pivot block Pinv, the rest
+//     A_ij - A_iK Pinv A_Kj;
 //   * lane group lk needs row lk of Pinv only.  It reads the pivot block through the cyclic permutation that puts row lk
-//     first and evaluates ONE row of the adjugate (three cofactors instead of six, no selects); the determinant is taken
-//     from lane 0 for everybody.  A symmetric pair of entries comes out of the same two products rounded the same way in
-//     both groups, so the inverse is bitwise symmetric - the sweep relies on it (rows taken from differently rounded
-//     inverses were measured to cost four digits of the factor).
+//     first and evaluates ONE row of the adjugate (three cofactors, no selects); the determinant is taken from lane 0 for
+//     everybody.  A symmetric pair of entries comes out of the same two products rounded the same way in both groups, so
+//     the inverse is bitwise symmetric - the sweep relies on it (rows taken from differently rounded inverses were
+//     measured to cost four digits of the factor).
 template <int NSTEPS>
 __device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4][64], double (*pblk)[16], const int wave, const int lane)
 {
     const int lr = lane % 16, lk = lane / 16;
     const int g = lk < 3 ? lk : 0;                       // the padding group computes group 0's row and multiplies zeros with it
     const int p0 = g, p1 = (g + 1) % 3, p2 = (g + 2) % 3;
-    // strip rows this lane reads: its operand row (zeros for the padding k = 3) and the three pivot rows in permuted order
-    const int zb = (lk < 3 ? lk : 3) * 64;
-    const int za0 = (lk < 3 ? p0 : 3) * 64, za1 = (lk < 3 ? p1 : 3) * 64, za2 = (lk < 3 ? p2 : 3) * 64;
     // the pivot block is read from its upper triangle only (the accumulators are symmetric up to rounding; every group must
     // see the same numbers)
     const int u01 = (p0 < p1 ? p0 : p1) * 3 + (p0 < p1 ? p1 : p0), u02 = (p0 < p2 ? p0 : p2) * 3 + (p0 < p2 ? p2 : p0),
               u12 = (p1 < p2 ? p1 : p2) * 3 + (p1 < p2 ? p2 : p1);
-    const int i_row = 16 * wave + lr;                    // the row this lane feeds to the A operand
+    // strip rows this lane reads: its B operand row (zeros for the padding k = 3) and the three pivot rows in permuted order
+    const int zb = (lk < 3 ? lk : 3) * 64 + 16 * wave + lr;
+    const int za0 = (lk < 3 ? p0 : 3) * 64 + lr, za1 = (lk < 3 ? p1 : 3) * 64 + lr, za2 = (lk < 3 ? p2 : 3) * 64 + lr;
+    const int jcol = 16 * wave + lr;                     // the column this lane holds
     if (threadIdx.x < 128) strips[threadIdx.x / 64][3][threadIdx.x % 64] = 0.0;
     bool ok = true;
-#pragma unroll
-    for (int kb = 0; kb < NSTEPS; kb++) {   // straight-line code: every register index below is static
+    // publish the pivot rows of step kb (static), then zero them.  Rows that sit in the same accumulator register (two steps
+    // in four all three do) go out with one store: lane group lk holds row k0 + (lk - k0 % 4).
+    auto publish = [&](const int kb) __attribute__((always_inline)) {
         const int k0 = 3 * kb;
         double* strip = &strips[kb & 1][0][0];
         double* pb = &pblk[kb & 1][0];
-        // pivot rows -> LDS (row k0 + c lives in wave (k0+c)/16, accumulator register ((k0+c)%16)/4, lane group (k0+c)%4)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const int row = k0 + c;
-            if (wave == row / 16 && lk == row % 4) {
-#pragma unroll
-                for (int tj = 0; tj < 4; tj++) {
-                    const int j = 16 * tj + lr;
-                    double val = acc[tj][(row % 16) / 4];
-                    const bool tile_has_pcol = k0 + 2 >= 16 * tj && k0 < 16 * tj + 16;   // static
-                    if (tile_has_pcol) {
-                        const int cj = j - k0;
-                        if (cj >= 0 && cj < 3) {
-                            pb[c * 3 + cj] = val;
-                            val = cj == c ? 1.0 : 0.0;
-                        }
-                    }
-                    strip[c * 64 + j] = val;
-                    acc[tj][(row % 16) / 4] = 0.0;
+        const int cj = jcol - k0;                        // 0..2: this lane holds a pivot column
+        // group A: the rows in the register of row k0 (lane groups k0 % 4 ..), group B: the rest, in the next register
+        const int qa = k0 / 4, qb = (k0 + 2) / 4, nA = qa == qb ? 3 : 4 - k0 % 4;
+        {
+            const int c = lk - k0 % 4;
+            if (c >= 0 && c < nA) {
+                double val = acc[qa / 4][qa % 4];
+                if (cj >= 0 && cj < 3) {
+                    pb[c * 3 + cj] = val;
+                    val = cj == c ? 1.0 : 0.0;
                 }
+                strip[c * 64 + jcol] = val;
+                acc[qa / 4][qa % 4] = 0.0;
             }
         }
+        if (qb != qa) {
+            const int c = nA + lk;
+            if (c < 3) {
+                double val = acc[qb / 4][qb % 4];
+                if (cj >= 0 && cj < 3) {
+                    pb[c * 3 + cj] = val;
+                    val = cj == c ? 1.0 : 0.0;
+                }
+                strip[c * 64 + jcol] = val;
+                acc[qb / 4][qb % 4] = 0.0;
+            }
+        }
+    };
+    publish(0);
+    double aop_t[4] = {0.0, 0.0, 0.0, 0.0}, sv_t = 0.0;   // operands of the updates the previous step left for this one
+#pragma unroll
+    for (int kb = 0; kb < NSTEPS; kb++) {   // straight-line code: every register index below is static
+        const int k0 = 3 * kb;
+        const double* strip = &strips[kb & 1][0][0];
+        const double* pb = &pblk[kb & 1][0];
         __syncthreads();
         // requests first, arithmetic behind them
         const double a = pb[p0 * 4], b = pb[u01], c = pb[u02], d = pb[p1 * 4], e = pb[u12], f = pb[p2 * 4];
-        const double ac0 = strip[za0 + i_row], ac1 = strip[za1 + i_row], ac2 = strip[za2 + i_row];
-        double sv[4];
+        double ac[4][3];
 #pragma unroll
-        for (int tj = 0; tj < 4; tj++) sv[tj] = strip[zb + 16 * tj + lr];
+        for (int tr = 0; tr < 4; tr++) { ac[tr][0] = strip[za0 + 16 * tr]; ac[tr][1] = strip[za1 + 16 * tr]; ac[tr][2] = strip[za2 + 16 * tr]; }
+        const double sv = strip[zb];
+        // the previous step's updates of the tiles that did not hold this step's pivot rows: their matrix instructions run
+        // while the requests above are under way
+        if (kb > 0) {
+            const int m0 = k0 / 16, m1 = (k0 + 2) / 16;   // the tile rows the previous step updated before its exchange
+#pragma unroll
+            for (int tr = 0; tr < 4; tr++)
+                if (tr != m0 && tr != m1) acc[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop_t[tr], sv_t, acc[tr], 0, 0, 0);
+        }
         // row 0 of the inverse of the permuted block = row lk of Pinv in the column order p0 p1 p2
         const double c00 = __builtin_fma(d, f, -(e * e)), c01 = __builtin_fma(c, e, -(b * f)), c02 = __builtin_fma(b, e, -(c * d));
         const double det_own = __builtin_fma(a, c00, __builtin_fma(b, c01, c * c02));
@@ -212,17 +245,38 @@ __device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4
         double id = __builtin_amdgcn_rcp(det);
         id = id * (2.0 - det * id);
         id = id * (2.0 - det * id);
-        // A'[i][k = lk], i = 16 wave + lr
-        double aop = (ac0 * c00 + ac1 * c01 + ac2 * c02) * id;
-        aop = i_row < k0 + 3 ? aop : -aop;
+        const double r0 = c00 * id, r1 = c01 * id, r2 = c02 * id;
+        const int cj = jcol - k0;                        // 0..2: this lane holds a pivot column: base zero
+        const bool pcol = cj >= 0 && cj < 3;
+        // A'[i][k = lk], i = 16 tr + lr
+        auto operand = [&](const int tr) __attribute__((always_inline)) {
+            const double v = ac[tr][0] * r0 + ac[tr][1] * r1 + ac[tr][2] * r2;
+            return 16 * tr + lr < k0 + 3 ? v : -v;
+        };
+        const bool more = kb + 1 < NSTEPS;
+        const int n0 = more ? (k0 + 3) / 16 : -1, n1 = more ? (k0 + 5) / 16 : -1;   // static: the tile rows of the next pivot rows
+        // pivot columns start from zero: only the wave(s) that hold them (a scalar branch), the lanes under the execution mask
+        if (wave == k0 / 16 || wave == (k0 + 2) / 16) {
+            if (pcol) {
 #pragma unroll
-        for (int tj = 0; tj < 4; tj++) {
-            const bool tile_has_pcol = k0 + 2 >= 16 * tj && k0 < 16 * tj + 16;   // static
-            if (tile_has_pcol) {
-                const int cj = 16 * tj + lr - k0;
-                if (cj >= 0 && cj < 3) acc[tj] = double4_t{0.0, 0.0, 0.0, 0.0};
+                for (int tr = 0; tr < 4; tr++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) asm volatile("v_mov_b64 %0, 0" : "=v"(acc[tr][r]));
             }
-            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, sv[tj], acc[tj], 0, 0, 0);
+        }
+        if (more) {
+            // the tile row(s) of the next pivot rows now, their exchange behind them; the other tiles' operands are kept
+            acc[n0] = __builtin_amdgcn_mfma_f64_16x16x4f64(operand(n0), sv, acc[n0], 0, 0, 0);
+            if (n1 != n0) acc[n1] = __builtin_amdgcn_mfma_f64_16x16x4f64(operand(n1), sv, acc[n1], 0, 0, 0);
+#pragma unroll
+            for (int tr = 0; tr < 4; tr++)
+                if (tr != n0 && tr != n1) aop_t[tr] = operand(tr);
+            sv_t = sv;
+            __builtin_amdgcn_sched_barrier(0);   // the operands above fill the wait for the matrix instruction's result
+            publish(kb + 1);
+        } else {
+#pragma unroll
+            for (int tr = 0; tr < 4; tr++) acc[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(operand(tr), sv, acc[tr], 0, 0, 0);
         }
     }
     return ok;
@@ -247,11 +301,11 @@ __global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrVie
     {
         const double* src = v.D + node * sb2;
 #pragma unroll
-        for (int tj = 0; tj < 4; tj++)
+        for (int tr = 0; tr < 4; tr++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int i = 16 * wave + 4 * r + lk, j = 16 * tj + lr;
-                acc[tj][r] = (i < sb && j < sb) ? src[(size_t)i * sb + j] : (i == j ? 1.0 : 0.0);   // identity padding: extra steps are harmless
+                const int i = 16 * tr + 4 * r + lk, j = 16 * wave + lr;      // wave w: tile column w (gj_sweep)
+                acc[tr][r] = (i < sb && j < sb) ? src[(size_t)i * sb + j] : (i == j ? 1.0 : 0.0);   // identity padding: extra steps are harmless
             }
     }
 
@@ -259,9 +313,9 @@ __global__ __launch_bounds__(kCrInvertThreads) void cr_invert_kernel(const CrVie
     if (!ok) scal[SC_LIN_STATUS] = 1.0;   // every lane tests its own part of the pivot blocks; all write the same word
     // symmetric to rounding; store the symmetrised inverse (coalesced, through an LDS image)
 #pragma unroll
-    for (int tj = 0; tj < 4; tj++)
+    for (int tr = 0; tr < 4; tr++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) X[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr] = acc[tj][r];
+        for (int r = 0; r < 4; r++) X[(16 * tr + 4 * r + lk) * kLd + 16 * wave + lr] = acc[tr][r];
     __syncthreads();
     double* dst = v.E + node * sb2;
     for (int i = wave; i < sb; i += kCrInvertThreads / 64)
@@ -533,15 +587,15 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
     double4_t acc[4];
     auto load_acc = [&](const double* img) __attribute__((always_inline)) {
 #pragma unroll
-        for (int tj = 0; tj < 4; tj++)
+        for (int tr = 0; tr < 4; tr++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[tj][r] = img[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr];
+            for (int r = 0; r < 4; r++) acc[tr][r] = img[(16 * tr + 4 * r + lk) * kLd + 16 * wave + lr];   // wave w: tile column w
     };
     auto store_acc = [&](double* img) __attribute__((always_inline)) {
 #pragma unroll
-        for (int tj = 0; tj < 4; tj++)
+        for (int tr = 0; tr < 4; tr++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) img[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr] = acc[tj][r];
+            for (int r = 0; r < 4; r++) img[(16 * tr + 4 * r + lk) * kLd + 16 * wave + lr] = acc[tr][r];
     };
     load_acc(IA);
     bool ok = gj_sweep<2 * kDense2Cams>(acc, strips, pblk, wave, lane);
@@ -556,10 +610,10 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
         }
         __syncthreads();
 #pragma unroll
-        for (int tj = 0; tj < 4; tj++) {    // S_C = C - B^T T
-            const double4_t p4 = mfma_ptq_tile(IB, IT, 16 * wave, 16 * tj, lane);
+        for (int tr = 0; tr < 4; tr++) {    // S_C = C - B^T T, straight into the sweep's layout (wave w: tile column w)
+            const double4_t p4 = mfma_ptq_tile(IB, IT, 16 * tr, 16 * wave, lane);
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[tj][r] = IC[(16 * wave + 4 * r + lk) * kLd + 16 * tj + lr] - p4[r];
+            for (int r = 0; r < 4; r++) acc[tr][r] = IC[(16 * tr + 4 * r + lk) * kLd + 16 * wave + lr] - p4[r];
         }
         __syncthreads();                    // gj_sweep rewrites the strips' zero rows: everyone is past the first sweep's reads
         ok = gj_sweep<2 * kDense2Cams>(acc, strips, pblk, wave, lane) && ok;
