@@ -513,6 +513,7 @@ __global__ __launch_bounds__(kCrReduceThreads) void cr_reduce_kernel(const CrVie
     }
 }
 
+
 // ---- small dense systems: two-block elimination by ONE workgroup on the matrix cores ---------------------------------------
 // The reference's sliding windows (slam.cpp:121-129) leave a dense reduced system of at most 19 free cameras (114 unknowns).
 // S = [A B; B^T C] with A the first ten cameras: E_A = A^-1 (register-resident block Gauss-Jordan sweep, as cr_invert),
