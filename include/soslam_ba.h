@@ -220,6 +220,15 @@ int soslam_ba_set_host_allreduce(soslam_ba* h, soslam_host_allreduce_fn fn, void
 int soslam_rccl_get_unique_id(void* id128);
 int soslam_ba_init_rccl(soslam_ba* h, const void* id128, int32_t rank, int32_t world);
 /*
+ * Sharded jobs: agree on a status word before a collective phase.  Every rank passes its own status (SOSLAM_OK or the error its
+ * set-up calls returned); *agreed receives the MAX over the ranks through the attached collective leg (one 8-byte all-reduce).
+ * A rank whose soslam_ba_set_problem / set_state failed must NOT simply skip soslam_ba_solve - the other ranks would wait for it
+ * in their first all-reduce, and RCCL has no time-out: all ranks call this instead and leave together when *agreed != SOSLAM_OK.
+ * Without a collective attached *agreed = local_status.  (A rank that cannot join the communicator at all - a failed
+ * soslam_ba_init_rccl - is beyond what the library can agree on: that needs the host's launcher.)
+ */
+int soslam_ba_agree_status(soslam_ba* h, int local_status, int* agreed);
+/*
  * After a sharded solve: poses[n_cam*6] (replicated, may be NULL) and the points of ALL ranks, points_global[n_pt_global*3],
  * on every rank - this rank's shard is the global range [shard_begin, shard_begin + n_pt).  One all-reduce (sum of
  * zero-padded shards) through the RCCL leg or the callback; with one rank it is a plain download.

@@ -104,6 +104,7 @@ int soslam_ba_get_state(soslam_ba* h, double* poses, double* points)
 int soslam_rccl_get_unique_id(void* id128) { memset(id128, 0, 128); return SOSLAM_OK; }
 int soslam_ba_init_rccl(soslam_ba* h, const void* id128, int32_t rank, int32_t world) { (void)h; (void)id128; return (rank == 0 && world == 1) ? SOSLAM_OK : SOSLAM_ERR_COMM; }
 int soslam_ba_set_covisibility(soslam_ba* h, uint64_t n, const uint32_t* a, const uint32_t* b) { (void)h; (void)n; (void)a; (void)b; return SOSLAM_OK; }
+int soslam_ba_agree_status(soslam_ba* h, int local_status, int* agreed) { (void)h; if (agreed) *agreed = local_status; return SOSLAM_OK; }   /* one rank */
 void soslam_ba_shard_range(uint32_t n_pt, int32_t rank, int32_t world, uint32_t* begin, uint32_t* end)
 {
     if (world < 1) world = 1;

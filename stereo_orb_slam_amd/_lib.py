@@ -87,7 +87,7 @@ BA_SYMBOLS = [
     "soslam_ba_destroy", "soslam_ba_set_options", "soslam_ba_set_projection", "soslam_ba_set_problem", "soslam_ba_set_state",
     "soslam_ba_get_state", "soslam_ba_solve", "soslam_ba_iterate", "soslam_ba_get_iteration_log",
     "soslam_ba_optimize", "soslam_ba_set_covisibility", "soslam_ba_set_allreduce", "soslam_ba_reduce_buffer_count", "soslam_ba_set_reduce_buffer",
-    "soslam_ba_set_host_allreduce", "soslam_rccl_get_unique_id", "soslam_ba_init_rccl", "soslam_ba_get_state_global",
+    "soslam_ba_set_host_allreduce", "soslam_rccl_get_unique_id", "soslam_ba_init_rccl", "soslam_ba_agree_status", "soslam_ba_get_state_global",
     "soslam_ba_shard_range", "soslam_ba_time_kernel", "soslam_ba_debug_step", "soslam_ba_debug_read",
     "soslam_pose_from_global_matrix", "soslam_global_matrix_from_pose",
 ]

@@ -163,6 +163,13 @@ class BundleAdjustment:
         buf = C.create_string_buffer(bytes(unique_id), _lib.RCCL_UNIQUE_ID_BYTES)
         _lib.check(self._L.soslam_ba_init_rccl(self._h, C.cast(buf, C.c_void_p), rank, world), "soslam_ba_init_rccl")
 
+    def agree_status(self, local_status: int) -> int:
+        """MAX of the ranks' status words through the attached collective (soslam_ba_agree_status): a rank whose set-up failed
+        calls this instead of skipping the solve, so that the other ranks do not wait for it in their first all-reduce."""
+        out = C.c_int(local_status)
+        _lib.check(self._L.soslam_ba_agree_status(self._h, int(local_status), C.byref(out)), "soslam_ba_agree_status")
+        return out.value
+
     def get_state_global(self, n_pt_global: int, shard_begin: int):
         """Poses and the points of all ranks (soslam_ba_get_state_global)."""
         c, p = np.zeros((self.n_cam, 6)), np.zeros((n_pt_global, 3))

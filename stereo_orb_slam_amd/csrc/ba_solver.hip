@@ -132,6 +132,7 @@ struct soslam_ba {
     bool collective() const { return rccl != nullptr || allreduce != nullptr || host_allreduce != nullptr; }
     bool stop_agreed = false;           // multi-rank: some rank voted to end the solve (time limit) in the last iteration
     DevBuf<double> gather;              // soslam_ba_get_state_global: all ranks' points
+    DevBuf<double> agree;               // soslam_ba_agree_status: one word
     DevBuf<double> ls_tile, ls_part;    // line-search trial: per-tile {rho, direction . gradient}, per-block {|step|^2, max |delta|}
 
     // trust region
@@ -420,7 +421,16 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             fc.clear();
             for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
                 const int32_t f = h->h_cam_free[q_cam[q]];
-                if (f >= 0 && (fc.empty() || fc.back() != (uint32_t)f)) fc.push_back((uint32_t)f);
+                if (f < 0) continue;
+                // A (camera, point) pair observed twice would own one window slot and one row of the pair table: the second row
+                // would be dropped from W while C, g_p, B and g_c (plain sums over the rows) kept it - an inconsistent reduced
+                // system.  Rejected here as it is for long-track points below (a point's observations are camera-ascending, so
+                // duplicates are neighbours); the reference's front end never produces them (one match per frame and point).
+                if (!fc.empty() && fc.back() == (uint32_t)f) {
+                    set_last_error("point %u is observed twice by camera %u", h->pt_int2user[p], q_cam[q]);
+                    return SOSLAM_ERR_INVALID_ARGUMENT;
+                }
+                fc.push_back((uint32_t)f);
             }
             if (p < n_short) max_track = std::max<uint32_t>(max_track, (uint32_t)fc.size());
             if (fc == fc_prev) continue;   // neighbouring points mostly share their camera set: its pairs are marked already
@@ -559,7 +569,16 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             fc.clear();
             for (uint32_t q = pt_start[p]; q < pt_start[p + 1]; q++) {
                 const int32_t f = h->h_cam_free[q_cam[q]];
-                if (f >= 0 && (fc.empty() || fc.back() != (uint32_t)f)) fc.push_back((uint32_t)f);
+                if (f < 0) continue;
+                // A (camera, point) pair observed twice would own one window slot and one row of the pair table: the second row
+                // would be dropped from W while C, g_p, B and g_c (plain sums over the rows) kept it - an inconsistent reduced
+                // system.  Rejected here as it is for long-track points below (a point's observations are camera-ascending, so
+                // duplicates are neighbours); the reference's front end never produces them (one match per frame and point).
+                if (!fc.empty() && fc.back() == (uint32_t)f) {
+                    set_last_error("point %u is observed twice by camera %u", h->pt_int2user[p], q_cam[q]);
+                    return SOSLAM_ERR_INVALID_ARGUMENT;
+                }
+                fc.push_back((uint32_t)f);
             }
             if (p > chunk_p0 && p - chunk_p0 < chunk_pts_max && fc == fc_last) continue;   // same camera set as the point before: the window does not change
             merged.clear();
@@ -1777,6 +1796,34 @@ int soslam_ba_get_state_global(soslam_ba* h, double* poses, uint32_t n_pt_global
     SOSLAM_HIP_CHECK(hipMemcpyAsync(points_global, h->gather.p, sizeof(double) * 3 * (size_t)n_pt_global, hipMemcpyDeviceToHost, s));
     if (poses) SOSLAM_HIP_CHECK(hipMemcpyAsync(poses, h->cams[h->cur].p, sizeof(double) * 6 * h->n_cam, hipMemcpyDeviceToHost, s));
     SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return SOSLAM_OK;
+}
+
+int soslam_ba_agree_status(soslam_ba* h, int local_status, int* agreed)
+{
+    if (!h || !agreed) return SOSLAM_ERR_INVALID_ARGUMENT;
+    *agreed = local_status;
+    if (!h->collective()) return SOSLAM_OK;
+    SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    double* word = nullptr;
+    if (h->rccl || h->host_allreduce) {
+        SOSLAM_CHECK(h->agree.alloc(8));
+        word = h->agree.p;
+    } else if (h->have_problem && h->reduce) {
+        word = h->scalp() + SC_STOP;    // a device callback may only accept ranges of the reduce buffer it was given
+    } else {
+        set_last_error("agree_status: the device-callback leg has no buffer before set_problem");
+        return SOSLAM_ERR_COMM;
+    }
+    const double mine = local_status == SOSLAM_OK ? 0.0 : (double)local_status;
+    double all = 0.0;
+    SOSLAM_HIP_CHECK(hipMemcpyAsync(word, &mine, sizeof mine, hipMemcpyHostToDevice, s));
+    SOSLAM_CHECK(do_allreduce(h, word, 1, SOSLAM_REDUCE_MAX));
+    SOSLAM_HIP_CHECK(hipMemcpyAsync(&all, word, sizeof all, hipMemcpyDeviceToHost, s));
+    SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (word != h->agree.p) SOSLAM_HIP_CHECK(hipMemsetAsync(word, 0, sizeof(double), s));
+    *agreed = (int)all;
     return SOSLAM_OK;
 }
 

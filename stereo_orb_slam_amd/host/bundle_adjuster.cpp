@@ -119,7 +119,17 @@ void BundleAdjuster::Optimize(unsigned int start_frame_id, unsigned int end_fram
             m_status = soslam_ba_set_problem(m_handle, n_cam, pe - pb, (uint32_t)s_cam.size(), s_cam.data(), s_pt.data(), s_uv.data(),
                                              fixed.data());
         if (m_status == SOSLAM_OK) m_status = soslam_ba_set_state(m_handle, poses.data(), points.data() + 3 * (size_t)pb);
+        // A rank whose set-up failed (a rank-specific limit, a malformed shard) must not leave the others waiting in the solve's
+        // first all-reduce: the ranks agree on one status word and leave together.  Needs the communicator (m_comm_ready).
+        auto agree = [&]() {
+            if (!m_comm_ready) return;
+            int all = m_status;
+            const int st = soslam_ba_agree_status(m_handle, m_status, &all);
+            if (m_status == SOSLAM_OK && (st != SOSLAM_OK || all != SOSLAM_OK)) m_status = st != SOSLAM_OK ? st : SOSLAM_ERR_COMM;   // a peer failed
+        };
+        agree();
         if (m_status == SOSLAM_OK) m_status = soslam_ba_solve(m_handle, &m_summary);
+        agree();
         // poses are replicated; the points of all ranks come together with one all-reduce
         if (m_status == SOSLAM_OK) m_status = soslam_ba_get_state_global(m_handle, poses.data(), n_pt, pb, points.data());
     } else {

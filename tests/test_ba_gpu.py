@@ -378,6 +378,38 @@ def test_errors_leave_caller_arrays_untouched(gpu, prob1):
     np.testing.assert_array_equal(p, p0)
 
 
+def test_duplicate_observations_are_rejected(gpu, prob1):
+    """A (camera, point) pair observed twice owns one window slot: its second row would drop out of W while C, g_p, B and g_c
+    kept it.  The library refuses such a problem - on the windowed path and on the long-track path alike - with
+    SOSLAM_ERR_INVALID_ARGUMENT; a point seen twice by a FIXED camera is legal (its rows only enter the point block)."""
+    ba, synth, L = gpu
+    k = int(np.flatnonzero(prob1.obs_cam == 3)[0])          # an observation of a free camera
+    dup = lambda a: np.ascontiguousarray(np.concatenate([a, a[k:k + 1]]))
+    with ba.BundleAdjustment() as h:
+        h.set_projection(prob1.proj_l, prob1.proj_r)
+        with pytest.raises(L.SoslamError) as e:
+            h.set_problem(prob1.n_cam, prob1.n_pt, dup(prob1.obs_cam), dup(prob1.obs_pt), dup(prob1.obs_uv), prob1.cam_fixed)
+        assert e.value.status == L.ERR_INVALID_ARGUMENT and "observed twice" in str(e.value)
+    # long-track path: one point seen by 40 cameras, one of them twice
+    long = synth.generate_ba(None, n_cam=40, n_pt=50, track_mode=1, track_len=40)
+    k = int(np.flatnonzero(long.obs_cam == 20)[0])
+    dup = lambda a: np.ascontiguousarray(np.concatenate([a, a[k:k + 1]]))
+    with ba.BundleAdjustment() as h:
+        h.set_projection(long.proj_l, long.proj_r)
+        with pytest.raises(L.SoslamError) as e:
+            h.set_problem(long.n_cam, long.n_pt, dup(long.obs_cam), dup(long.obs_pt), dup(long.obs_uv), long.cam_fixed)
+        assert e.value.status == L.ERR_INVALID_ARGUMENT
+    # the fixed camera (camera 0) may see a point twice
+    k = int(np.flatnonzero(prob1.obs_cam == 0)[0])
+    dup = lambda a: np.ascontiguousarray(np.concatenate([a, a[k:k + 1]]))
+    with ba.BundleAdjustment(ba.default_options(max_iterations=3)) as h:
+        h.set_projection(prob1.proj_l, prob1.proj_r)
+        h.set_problem(prob1.n_cam, prob1.n_pt, dup(prob1.obs_cam), dup(prob1.obs_pt), dup(prob1.obs_uv), prob1.cam_fixed)
+        h.set_state(prob1.poses_cw(), prob1.points_f64())
+        s = h.solve()
+        assert s.final_cost < s.initial_cost
+
+
 def test_optimize_one_call(gpu, oracle_lib, prob1):
     ba, synth, L = gpu
     cams, pts, summ = ba.optimize(prob1, ba.default_options(max_iterations=10))

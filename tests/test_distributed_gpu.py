@@ -162,3 +162,57 @@ def test_native_rccl_leg_one_rank(tmp_path):
     r0 = np.load(tmp_path / "rank0.npz")
     assert r0["accepted"].all()
     assert np.array_equal(r0["cost"], ref_cost) and np.array_equal(r0["cams"], ref_cams)
+
+
+def _failing_worker(rank, world, port, out_dir):
+    """Rank 1's shard is malformed (a point observed twice by one camera): its set_problem fails.  Both ranks must learn of it
+    through soslam_ba_agree_status and leave together instead of rank 0 waiting in the solve's first all-reduce."""
+    import torch
+    import torch.distributed as dist
+
+    from stereo_orb_slam_amd import _lib, ba, distributed, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = synth.generate_ba(1)
+    with ba.BundleAdjustment(ba.default_options(device=0, linear_solver=2)) as h:
+        distributed.attach(h, rank, world, torch.device("cuda", 0))   # the host leg: no problem is needed for it
+        shard = full.shard(rank, world)
+        status = 0
+        try:
+            h.set_covisibility(full.covisibility_pairs())
+            if rank == 1:
+                k = int(np.flatnonzero(shard.obs_cam != 0)[0])     # an observation of a free camera
+                dup = lambda a: np.ascontiguousarray(np.concatenate([a, a[k:k + 1]]))
+                h.set_projection(shard.proj_l, shard.proj_r)
+                h.set_problem(shard.n_cam, shard.n_pt, dup(shard.obs_cam), dup(shard.obs_pt), dup(shard.obs_uv), shard.cam_fixed)
+            else:
+                h.load(shard)
+        except _lib.SoslamError as e:
+            status = e.status
+        agreed = h.agree_status(status)
+        solved = False
+        if agreed == 0:
+            h.iterate(2)
+            solved = True
+    np.savez(os.path.join(out_dir, f"fail{rank}.npz"), status=status, agreed=agreed, solved=solved)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_does_not_hang_the_others(tmp_path):
+    """a set-up failure on one rank of a sharded job (here: a malformed shard) used to leave the other ranks in
+    the first all-reduce of their solve for ever.  soslam_ba_agree_status (one MAX all-reduce of a status word, which
+    BundleAdjuster::Optimize now calls before the solve and before the global read-back) lets every rank leave."""
+    import torch
+    import torch.multiprocessing as mp
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the HIP path has no fallback")
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "fail0.npz"), np.load(tmp_path / "fail1.npz")
+    assert int(r0["status"]) == 0 and int(r1["status"]) != 0
+    assert int(r0["agreed"]) == int(r1["agreed"]) != 0
+    assert not bool(r0["solved"]) and not bool(r1["solved"])
