@@ -1698,11 +1698,14 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
 {
     if (!n_chunks) return;
     if (kmax <= 10) {
-        // windows of at most 10 cameras: the pipelined kernel (46 KB of LDS, two workgroups of eight waves per CU)
-        static bool attr_set = false;   // once per process: the call is not free and sits right behind the host's decision
-        if (!attr_set) {
+        // windows of at most 10 cameras: the pipelined kernel (kS10Lds = 59 KB of LDS, two workgroups of eight waves per CU)
+        static bool attr_set[64] = {};   // once per DEVICE (the attribute belongs to the function on a device): the call is not free and sits right behind the host's decision
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev = dev >= 0 && dev < 64 ? dev : 0;
+        if (!attr_set[dev]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur10_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS10Lds);
-            attr_set = true;
+            attr_set[dev] = true;
         }
         hipLaunchKernelGGL(ba_schur10_kernel, dim3(n_chunks), dim3(kS10Threads), kS10Lds, s, chunks, batches, chunk_slab, chunk_cam, pair_row, ar,
                            campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal, pt_start, pt_obs, q_cam, q_slot, point_blocks_from_rows);

@@ -66,6 +66,9 @@ struct soslam_ba {
     int bw = 0;                         // block half-bandwidth of the reduced camera matrix
     bool pcg_band = false;              // PCG preconditioned by the band factor
     bool use_cr = false;                // band factor by block cyclic reduction (bw <= kCrBandMax)
+    bool off_band = false;              // some blocks of S lie outside the factored band bw (loop closures): they stay in the matvec only
+    int bw_full = 0;                    // the largest block offset when off_band
+    double comp_share = 0.0;            // off_band: share of the left-out blocks' absolute row sums added to the factored diagonal
     int cr_rounds = 1;                  // PCG rounds enqueued per solve with the exact band factor (see take_step)
     bool cr_factor_valid = false;       // cr_ws holds a factor of an earlier iteration's reduced matrix
     int solver = SOSLAM_SOLVER_PCG;
@@ -100,6 +103,8 @@ struct soslam_ba {
     uint32_t n_long = 0, n_long_pairs = 0, n_short = 0;
     DevBuf<uint32_t> row_ptr, ent_col, ent_blk, blk_row, blk_col;
     DevBuf<int32_t> cr_map;             // gather map of the cyclic-reduction assembly (crsolve.hip)
+    DevBuf<uint32_t> cr_comp_ptr, cr_comp_ent;   // off-band mode: per camera the blocks the map leaves out
+    DevBuf<double> cr_comp;             // their absolute row sums (diagonal compensation of the factored band)
 
     // state and work buffers
     DevBuf<double> cams[2], pts[2];
@@ -171,6 +176,11 @@ struct soslam_ba {
 namespace {
 
 LmDiag lm_diag(const soslam_ba* h, double radius) { return LmDiag{radius, h->opt.min_lm_diagonal, h->opt.max_lm_diagonal}; }
+
+// Ceres runs TrustRegionMinimizer::DoLineSearch only when the problem is constrained (options.is_constrained: some parameter has
+// a finite bound).  The reference bounds every point coordinate (/root/reference/src/bundle_adjuster.cpp:104-108), so its problems
+// always are; a C-ABI caller with infinite bounds gets plain trust-region steps.
+bool is_constrained(const soslam_ba* h) { return std::isfinite(h->opt.lower_bound) || std::isfinite(h->opt.upper_bound); }
 
 // ---- profiling marks ---------------------------------------------------------------------------------
 
@@ -687,6 +697,35 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     h->bw = 0;
     for (uint32_t b = 0; b < h->n_blocks; b++) h->bw = std::max<int>(h->bw, (int)(h->h_blk_col[b] - h->h_blk_row[b]));
     const bool band_fits = h->bw <= kBandMax;
+    // Loop closures - the global BA after a pose-graph run, /root/reference/src/pose_graph_optimizer.cpp:95, slam.cpp:156 - put a
+    // few blocks far off a band that holds everything else.  The band the PRECONDITIONER factors is then the narrowest one
+    // that holds 99 % of the blocks (h->bw); the blocks outside it stay in S, i.e. in the PCG's matrix-vector product, and
+    // only leave the factor: k closure blocks perturb the preconditioned matrix by a term of rank <= 12 k, which costs
+    // conjugate gradients about that many extra rounds instead of the thousands block-Jacobi needs on a long chain.
+    h->off_band = false;
+    if (!band_fits && h->n_blocks > 0) {
+        std::vector<uint32_t> hist((size_t)h->bw + 1, 0);
+        for (uint32_t b = 0; b < h->n_blocks; b++) hist[h->h_blk_col[b] - h->h_blk_row[b]]++;
+        uint64_t acc = 0;
+        int w = 0;
+        for (; w <= h->bw; w++) {
+            acc += hist[(size_t)w];
+            if (acc * 100 >= (uint64_t)h->n_blocks * 99) break;
+        }
+        // Only then: a band wider than the cyclic reduction takes (tracks longer than ten cameras on a long chain) cut at that
+        // limit leaves out a large share of every point's coupling; the truncated band then loses positive definiteness once the
+        // damping is small, and the diagonal compensation that restores it (take_step) stiffens the smooth modes - measured
+        // (scripts/offband_probe.py): 120 cameras with 10 % of tracks of length 20: 480 rounds against block-Jacobi's 340 much
+        // cheaper iterations; 150 cameras, tracks of 24: 340 against 180.  Such problems keep the block-Jacobi PCG.
+        if (w > kCrBandMax) w = 0;
+        if (w >= 1 && std::getenv("SOSLAM_NO_CR") == nullptr && std::getenv("SOSLAM_NO_OFFBAND") == nullptr &&
+            h->opt.linear_solver != SOSLAM_SOLVER_BAND_CHOLESKY &&
+            h->opt.linear_solver != SOSLAM_SOLVER_DENSE_CHOLESKY && !(h->opt.linear_solver == SOSLAM_SOLVER_AUTO && nf * 6 <= (uint32_t)kDenseAutoLimit)) {
+            h->off_band = true;
+            h->bw_full = h->bw;
+            h->bw = w;
+        }
+    }
     h->solver = h->opt.linear_solver;
     if (h->solver == SOSLAM_SOLVER_AUTO)
         h->solver = band_fits ? SOSLAM_SOLVER_BAND_CHOLESKY
@@ -695,7 +734,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         set_last_error("band Cholesky requested but the reduced matrix spans %d block diagonals (limit %d)", h->bw, kBandMax);
         return SOSLAM_ERR_INVALID_ARGUMENT;
     }
-    h->pcg_band = h->solver == SOSLAM_SOLVER_PCG && band_fits;
+    h->pcg_band = h->solver == SOSLAM_SOLVER_PCG && (band_fits || h->off_band);
 
     SETUP_MARK("solver choice");
     // uploads
@@ -774,7 +813,8 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     } else {
         h->dense.release();
     }
-    h->cr_rounds = 1;
+    h->cr_rounds = h->off_band ? 8 : 1;
+    h->comp_share = 0.0;
     h->cr_factor_valid = false;
     h->use_cr = (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) && h->bw >= 1 && h->bw <= kCrBandMax && nf > 0 &&
                 std::getenv("SOSLAM_NO_CR") == nullptr;
@@ -783,6 +823,13 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         std::vector<int32_t> map(cr_map_count(nf, h->bw));
         cr_build_map(nf, h->bw, h->n_blocks, h->h_blk_row.data(), h->h_blk_col.data(), map.data());
         SOSLAM_CHECK(h->cr_map.upload(map, s));
+        if (h->off_band) {
+            std::vector<uint32_t> cptr, cent;
+            cr_build_comp_lists(nf, h->bw, h->n_blocks, h->h_blk_row.data(), h->h_blk_col.data(), cptr, cent);
+            SOSLAM_CHECK(h->cr_comp_ptr.upload(cptr, s));
+            SOSLAM_CHECK(h->cr_comp_ent.upload(cent, s));
+            SOSLAM_CHECK(h->cr_comp.alloc((size_t)nf * 6));
+        }
         h->band.release(); h->bandT.release(); h->band_dinv.release();
     } else if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) {
         h->cr_ws.release();
@@ -1030,9 +1077,43 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                     launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), nullptr, &shift);
                     h->cr_factor_valid = true;
                 } else {
-                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp, nullptr, h->rhs());
+                if (!h->off_band) {
+                    launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp, nullptr, h->rhs());
+                } else {
+                    // The factored band leaves blocks of S out, and the band part of a positive definite matrix need not be
+                    // positive definite.  A breakdown must not become an invalid LM step (the reference's direct solver has
+                    // none): the host looks at the factorisation's status word - one synchronisation per iteration, in this mode
+                    // only - and refactors with a larger share of the left-out blocks' row sums on the diagonal (kept for the
+                    // following iterations; at share 1 the factored matrix is positive definite whatever was left out).
+                    launch_cr_comp(s, h->S(), h->n_free, h->cr_comp_ptr.p, h->cr_comp_ent.p, h->cr_comp.p);
+                    for (int attempt = 0; attempt < 6; attempt++) {
+                        launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), attempt == 0 ? &damp : nullptr, nullptr,
+                                         h->rhs(), h->cr_comp.p, h->comp_share);
+                        double st = 0.0;
+                        SOSLAM_HIP_CHECK(hipMemcpyAsync(&st, h->scalp() + SC_LIN_STATUS, sizeof st, hipMemcpyDeviceToHost, s));
+                        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+                        if (st == 0.0 || h->comp_share >= 1.0) break;
+                        SOSLAM_HIP_CHECK(hipMemsetAsync(h->scalp() + SC_LIN_STATUS, 0, sizeof(double), s));
+                        h->comp_share = h->comp_share == 0.0 ? 0.125 : std::min(1.0, 2.0 * h->comp_share);
+                    }
+                }
                 launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
                               h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, h->cr_rounds), h->scalp(), true);
+                if (h->off_band) {
+                    // this mode synchronises anyway (above): the solve runs to its tolerance here, in chunks of as many rounds as
+                    // the last solve used, instead of handing an unconverged step to the LM loop
+                    int enq = std::min(h->opt.pcg_max_iterations, h->cr_rounds);
+                    while (enq < h->opt.pcg_max_iterations) {
+                        double lin[3];
+                        SOSLAM_HIP_CHECK(hipMemcpyAsync(lin, h->scalp() + SC_LIN_ITERS, sizeof lin, hipMemcpyDeviceToHost, s));
+                        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+                        if (lin[1] <= h->opt.pcg_tolerance || lin[2] != 0.0) break;
+                        const int more = std::min(h->opt.pcg_max_iterations - enq, std::max(4, enq / 2));
+                        launch_pcg_cr_more(s, bsr_view(h), h->bw, h->cr_ws.p, h->dc_free.p, h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance, more,
+                                           h->scalp());
+                        enq += more;
+                    }
+                }
                 }
                 resid = h->lin_resid.p;
             } else if (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
@@ -1090,7 +1171,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                          h->scalp() + SC_MCC_CAM, h->cost_part.p, h->n_tiles, h->scalp() + SC_CAND_COST, h->scalp() + SC_GATE,
                          h->scalp() + SC_LIN_ITERS, h->x_cost, h->opt.min_relative_decrease, (spec && !h->collective()) ? 1 : 0,
                          stop_vote ? 1.0 : 0.0, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, published ? h->host_raw : nullptr, h->host_seq,
-                         published);
+                         published, is_constrained(h) ? 1 : 0);
         speculated = spec;
     }
     static_assert(4 + SC_COUNT <= 64, "one wave publishes the scalars");
@@ -1104,7 +1185,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
         // acceptance test on the summed scalars (identical on every rank), then the publication
         published = ++h->publish_seq;
         launch_gate_publish(s, h->scalp(), h->x_cost, h->opt.min_relative_decrease, speculated ? 1 : 0, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS,
-                            4, h->host_raw, h->host_seq, published);
+                            4, h->host_raw, h->host_seq, published, is_constrained(h) ? 1 : 0);
     }
     if (speculated) {
         const double* gate = h->scalp() + SC_GATE;
@@ -1130,9 +1211,19 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
     // tolerance.  Rounds are enqueued without host checks: if this solve fell short - the step is still a valid
     // inexact step, its residual enters the model cost change - the next solve enqueues one round more; if it was
     // done before its last round, the next one enqueues only as many as were used.
+    // The band part of a positive definite matrix need not be positive definite: if the factorisation of the truncated band
+    // broke down, this problem goes back to block-Jacobi PCG for good (the step just taken is invalid and is repeated).
+    if (h->off_band && h->use_cr && h->n_free && h->host_scal[SC_LIN_STATUS] == 1.0) {
+        h->off_band = false; h->use_cr = false; h->pcg_band = false;
+        h->bw = h->bw_full;
+    }
+    // With blocks outside the factored band (off_band) the factor is a preconditioner proper: more rounds, found the same way
+    // (twice as many after a solve that fell short, as many as were used after one that did not need them all).
     if (h->use_cr && h->pcg_band && h->n_free) {
         const int used = (int)h->host_scal[SC_LIN_ITERS];
-        if (h->host_scal[SC_LIN_RESID] > h->opt.pcg_tolerance) h->cr_rounds = std::min(h->cr_rounds + 1, 4);
+        const int cap = h->off_band ? h->opt.pcg_max_iterations : 4;
+        if (h->off_band) h->cr_rounds = std::max(2, std::min(used + 1, cap));   // the solve ran to its tolerance (take_step): one spare round
+        else if (h->host_scal[SC_LIN_RESID] > h->opt.pcg_tolerance) h->cr_rounds = std::min(h->cr_rounds + 1, cap);
         else if (used >= 1 && used < h->cr_rounds) h->cr_rounds = used;
     }
     return SOSLAM_OK;
@@ -1319,6 +1410,7 @@ int line_search(soslam_ba* h, const StepScalars& sc, double* step_size, double* 
     constexpr double kSufficientDecrease = 1e-4, kMaxContraction = 1e-3, kMinContraction = 0.6, kMinStepSize = 1e-9;
     constexpr int kMaxIterations = 20;
     *step_size = 1.0;
+    if (!is_constrained(h)) return SOSLAM_OK;                                          // unconstrained problem: Ceres does not search
     if (sc.cand_cost <= sc.x_cost + kSufficientDecrease * sc.gdot) return SOSLAM_OK;   // the full step satisfies Armijo
     const double step2_cam_full = h->host_scal[SC_STEP2_CAM];
     LsSample initial, previous, current;

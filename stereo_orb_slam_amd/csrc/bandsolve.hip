@@ -647,8 +647,21 @@ void launch_pcg_cr(hipStream_t s, const BsrView& A, int bw, double* cr_ws, const
     launch_cr_solve(s, A.n_rows, bw, cr_ws, b, z, nullptr, forward_done);   // the factorisation may have carried b down the tree
     hipLaunchKernelGGL(pcg_band_matvec_kernel, dim3(n_wg), dim3(256), 0, s, A, z, q, part, nullptr);
     hipLaunchKernelGGL(pcg_first_update_kernel, dim3(1), dim3(1024), 0, s, n, n_wg, part, b, z, q, x, resid, p, state, tol, scal);
-    for (int round = 1; round < max_rounds; round++) {
-        // every kernel of a later round returns at once when the previous round converged (device-side flag)
+    launch_pcg_cr_more(s, A, bw, cr_ws, x, resid, work, tol, max_rounds - 1, scal);
+}
+
+// further rounds of a solve launch_pcg_cr began (its state lies in work): each returns at once when an earlier round converged
+void launch_pcg_cr_more(hipStream_t s, const BsrView& A, int bw, double* cr_ws, double* x, double* resid, double* work, double tol, int rounds,
+                        double* scal)
+{
+    if (!A.n_rows) return;
+    const uint32_t n = A.n_rows * 6, n_wg = pcg_band_matvec_blocks(n);
+    double* p = work;
+    double* z = work + n;
+    double* q = work + 2 * (size_t)n;
+    double* state = work + 3 * (size_t)n;
+    double* part = state + PS_COUNT;
+    for (int round = 0; round < rounds; round++) {
         launch_cr_solve(s, A.n_rows, bw, cr_ws, resid, z, state + PS_DONE);
         hipLaunchKernelGGL(pcg_direction_kernel, dim3(1), dim3(1024), 0, s, n, resid, z, p, state);
         hipLaunchKernelGGL(pcg_band_matvec_kernel, dim3(n_wg), dim3(256), 0, s, A, p, q, part, state);

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "ba_kernels.h"
 #include "reduce.h"
@@ -58,6 +59,7 @@ __device__ __forceinline__ double4_t mfma_ptq_tile(const double* __restrict__ P,
 
 struct CrView {
     uint32_t m;       // super-blocks
+    uint32_t n_real;  // scalar rows of the system (the rest of the last super-block is padding)
     int bw, sb;       // cameras per super-block, scalars per super-block
     double *D, *F, *E, *P, *Q, *PT, *QT, *F2;   // each [m][sb*sb], row-major; P, Q (and transposes) indexed by the eliminated node;
                                                 // F2: the couplings of the next level (cr_reduce reads one of F / F2 and writes the other)
@@ -67,7 +69,7 @@ struct CrView {
 // (cr_build_map): every element of both arrays is written - a 6x6 block of S, its transpose, zero, or the unit
 // diagonal of a padding camera - so no memset precedes it.  blockIdx = (super-block, 0: D / 1: F).
 __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blocks, const int32_t* __restrict__ map, const CrView v,
-                                                        const CamDamp damp, const CrShift shift)
+                                                        const CamDamp damp, const CrShift shift, const double* __restrict__ comp, const double comp_scale)
 {
     const int sb = v.sb, bw = v.bw;
     const uint32_t i = blockIdx.x;
@@ -102,6 +104,14 @@ __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blo
     if (shift.diagB && !is_f) {
         const uint32_t u = i * (uint32_t)sb + (uint32_t)c;
         if (u < shift.n_free * 6) extra = point_lambda(shift.diagB[u], shift.sc[u], shift.lm) - shift.lc[u];
+    }
+    // blocks of S outside the block-tridiagonal part are not factored (off-band mode).  The band part of a positive definite
+    // matrix need not be positive definite; a share comp_scale of the left-out blocks' absolute row sums on the diagonal makes
+    // it so (at comp_scale = 1 the factored matrix exceeds S by a diagonally dominant one) - the caller raises the share only
+    // when a factorisation breaks down, because what is added here weakens the preconditioner on the smooth modes
+    if (comp && !is_f) {
+        const uint32_t u = i * (uint32_t)sb + (uint32_t)c;
+        if (u < v.n_real) extra += comp_scale * comp[u];
     }
 #pragma unroll 4
     for (int r = threadIdx.x / 64; r < sb; r += 4) {
@@ -1111,6 +1121,7 @@ CrView make_view(uint32_t n_rows, int bw, double* ws)
     CrView v;
     v.bw = bw; v.sb = 6 * bw;
     v.m = (n_rows + (uint32_t)bw - 1) / (uint32_t)bw;
+    v.n_real = n_rows * 6;
     const size_t per = (size_t)v.m * v.sb * v.sb;
     v.D = ws; v.F = ws + per; v.E = ws + 2 * per; v.P = ws + 3 * per; v.Q = ws + 4 * per; v.PT = ws + 5 * per; v.QT = ws + 6 * per;
     v.F2 = ws + 7 * per;
@@ -1150,7 +1161,9 @@ void cr_build_map(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* bl
         const uint32_t ia = ca / (uint32_t)bw, ib = cb / (uint32_t)bw;
         const uint32_t la = ca - ia * (uint32_t)bw, lb = cb - ib * (uint32_t)bw;
         if (ia == ib) map[((size_t)ia * bw + la) * bw + lb] = (int32_t)b;
-        else map[per + ((size_t)ib * bw + lb) * bw + la] = (int32_t)b;   // F_ib: row camera cb, column camera ca
+        else if (ib == ia + 1) map[per + ((size_t)ib * bw + lb) * bw + la] = (int32_t)b;   // F_ib: row camera cb, column camera ca
+        // else: a block outside the block-tridiagonal part (a loop closure: the caller factors the band without it and keeps the
+        // block in the matrix-vector product of its PCG)
     }
 }
 
@@ -1164,15 +1177,53 @@ static int cr_fwd_pairs(uint32_t m)
     return pairs;
 }
 
+// comp[6 f + a] = sum over the blocks of S that the map leaves out (cr_build_map) of the absolute values in scalar row 6 f + a;
+// lists: per camera the left-out blocks it belongs to (side 0: as their row camera, 1: as their column camera), host-built
+__global__ __launch_bounds__(256) void cr_comp_kernel(const double* __restrict__ blocks, const uint32_t n6, const uint32_t* __restrict__ ptr,
+                                                      const uint32_t* __restrict__ ent, double* __restrict__ comp)
+{
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n6) return;
+    const uint32_t f = u / 6, a = u % 6;
+    double sum = 0.0;
+    for (uint32_t e = ptr[f]; e < ptr[f + 1]; e++) {
+        const uint32_t id = ent[e] >> 1, side = ent[e] & 1;
+        const double* B = blocks + 36 * (size_t)id;
+#pragma unroll
+        for (int c = 0; c < 6; c++) sum += fabs(side ? B[c * 6 + a] : B[a * 6 + c]);
+    }
+    comp[u] = sum;
+}
+
+void launch_cr_comp(hipStream_t s, const double* blocks, uint32_t n_rows, const uint32_t* ptr, const uint32_t* ent, double* comp)
+{
+    if (!n_rows) return;
+    hipLaunchKernelGGL(cr_comp_kernel, dim3((n_rows * 6 + 255) / 256), dim3(256), 0, s, blocks, n_rows * 6, ptr, ent, comp);
+}
+
+// host: the blocks cr_build_map leaves out, per camera (entry = 2 * block + side)
+void cr_build_comp_lists(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, std::vector<uint32_t>& ptr,
+                         std::vector<uint32_t>& ent)
+{
+    std::vector<std::vector<uint32_t>> lists(n_rows);
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const uint32_t ia = blk_row[b] / (uint32_t)bw, ib = blk_col[b] / (uint32_t)bw;
+        if (ib > ia + 1) { lists[blk_row[b]].push_back(2 * b); lists[blk_col[b]].push_back(2 * b + 1); }
+    }
+    ptr.assign(n_rows + 1, 0);
+    ent.clear();
+    for (uint32_t f = 0; f < n_rows; f++) { ptr[f + 1] = ptr[f] + (uint32_t)lists[f].size(); ent.insert(ent.end(), lists[f].begin(), lists[f].end()); }
+}
+
 void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp,
-                      const CrShift* shift, const double* fwd_b)
+                      const CrShift* shift, const double* fwd_b, const double* comp, double comp_scale)
 {
     if (!A.n_rows) return;
     const CrView v = make_view(A.n_rows, bw, ws);
     CamDamp none{};
     CrShift no_shift{};
     hipLaunchKernelGGL(cr_gather_kernel, dim3(v.m, 2), dim3(256), 0, s, const_cast<double*>(A.blocks), map, v, damp ? *damp : none,
-                       shift ? *shift : no_shift);
+                       shift ? *shift : no_shift, comp_scale > 0.0 ? comp : nullptr, comp_scale);
     const size_t lds_r = sizeof(double) * 4 * kImgRows * kLd;
     if (lds_r > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
     const uint32_t nt = ((uint32_t)v.sb + 15) / 16;
@@ -1253,10 +1304,13 @@ void launch_dense2_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, con
 {
     if (!A.n_rows) return;
     const size_t lds = sizeof(double) * 4 * 64 * kLd;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};     // per device: the attribute belongs to the function on that device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev >= 0 && dev < 64 ? dev : 0;
+    if (!attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense2_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(dense2_solve_kernel, dim3(1), dim3(kDense2Threads), lds, s, A, n_blocks, blk_row, blk_col, b, x, scal);
 }

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 namespace soslam {
 
@@ -92,14 +93,22 @@ struct CamDamp;
 struct CrShift;   // ba_kernels.h: the factor is made for another damping than the one S carries
 // fwd_b != NULL: the factorisation also carries the forward sweep of the solve that follows for this right-hand side (the
 // levels launch_cr_solve would run as pairs); that solve must then be called with forward_done = true and the same b
+// comp != NULL and comp_scale > 0 (off-band mode: some blocks of A lie outside the factored band): comp_scale * comp is added to
+// the diagonal of the factored matrix
 void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp,
-                      const CrShift* shift = nullptr, const double* fwd_b = nullptr);
+                      const CrShift* shift = nullptr, const double* fwd_b = nullptr, const double* comp = nullptr, double comp_scale = 0.0);
+// off-band mode: comp = absolute row sums of the blocks the map leaves out (lists from cr_build_comp_lists)
+void cr_build_comp_lists(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, std::vector<uint32_t>& ptr,
+                         std::vector<uint32_t>& ent);
+void launch_cr_comp(hipStream_t s, const double* blocks, uint32_t n_rows, const uint32_t* ptr, const uint32_t* ent, double* comp);
 // x = S^-1 b with the factors in ws; every launch returns at once when *done_flag != 0 (may be NULL)
 void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const double* b, double* x, const double* done_flag,
                      bool forward_done = false);
 // PCG rounds as launch_pcg_band, preconditioner = the cyclic-reduction factor
 void launch_pcg_cr(hipStream_t s, const BsrView& A, int bw, double* cr_ws, const double* b, double* x, double* resid, double* work,
                    double tol, int max_rounds, double* scal, bool forward_done = false);
+void launch_pcg_cr_more(hipStream_t s, const BsrView& A, int bw, double* cr_ws, double* x, double* resid, double* work, double tol, int rounds,
+                        double* scal);
 
 }  // namespace soslam
 

@@ -417,30 +417,68 @@ def test_optimize_one_call(gpu, oracle_lib, prob1):
     _compare_solutions(summ, cams, pts, osum, ocams, opts_)
 
 
-def test_block_jacobi_pcg_when_the_band_does_not_fit(gpu, oracle_lib, prob1):
-    """A loop-closure-like problem: an extra point seen by the first and last cameras of a longer chain puts a
-    block far off the diagonal, so the band factor is unavailable and PCG falls back to block-Jacobi."""
+def _with_loop_closures(synth, p, pairs, seed=5):
+    """p plus one far point per camera pair (a, b), observed by both: each puts a block far off the band of the reduced
+    camera matrix - what a loop closure does to the global BA (/root/reference/src/pose_graph_optimizer.cpp:95)."""
+    rng = np.random.default_rng(seed)
+    n = len(pairs)
+    extra_pts = p.points[:n].copy() + np.array([0, 0, 40.0], np.float32)
+    ids = np.arange(p.n_pt, p.n_pt + n, dtype=np.uint32)
+    ca = np.array([a for a, _ in pairs], np.uint32)
+    cb = np.array([b for _, b in pairs], np.uint32)
+    oc = np.concatenate([p.obs_cam, ca, cb])
+    op = np.concatenate([p.obs_pt, ids, ids])
+    uv = np.concatenate([p.obs_uv, rng.uniform(100, 1000, (2 * n, 4)).astype(np.float32)])
+    order = np.lexsort((op, oc))
+    return synth.BaProblem(p.poses_wc, np.concatenate([p.points, extra_pts]), oc[order], op[order], uv[order], p.proj_l, p.proj_r)
+
+
+def test_loop_closure_blocks_leave_the_factor_not_the_matrix(gpu, oracle_lib, prob1):
+    """A loop-closure-like problem: twenty points seen by the second and the last camera of a chain put ONE block far off the
+    band.  Round 2 took the band's width as the largest block offset, so this problem fell back to block-Jacobi PCG; now the
+    band that holds 99 % of the blocks is factored (cyclic reduction) and the off-band block stays in the PCG's matrix-vector
+    product only: the solve must reach its tolerance in at most 20 rounds, and S and the step must be the oracle's."""
     ba, synth, L = gpu
     p = synth.generate_ba(None, n_cam=30, n_pt=900, track_mode=0, track_len=5, spacing=0.5)
-    # tie camera 1 and camera 29 together through 20 far points observed by both
-    rng = np.random.default_rng(5)
-    extra_pts = p.points[:20].copy() + np.array([0, 0, 40.0], np.float32)
-    ids = np.arange(p.n_pt, p.n_pt + 20, dtype=np.uint32)
-    oc = np.concatenate([p.obs_cam, np.full(20, 1, np.uint32), np.full(20, 29, np.uint32)])
-    op = np.concatenate([p.obs_pt, ids, ids])
-    uv = np.concatenate([p.obs_uv, rng.uniform(100, 1000, (40, 4)).astype(np.float32)])
-    order = np.lexsort((op, oc))
-    q = synth.BaProblem(p.poses_wc, np.concatenate([p.points, extra_pts]), oc[order], op[order], uv[order], p.proj_l, p.proj_r)
+    q = _with_loop_closures(synth, p, [(1, 29)] * 20)
     ref = oracle_lib.step(q.obs_cam, q.obs_pt, q.obs_uv, q.poses_cw(), q.points_f64(), q.proj_l, q.proj_r, q.cam_fixed, 1e2)
-    with ba.BundleAdjustment(ba.default_options(linear_solver=2, pcg_tolerance=1e-13, pcg_max_iterations=3000)) as h:
+    with ba.BundleAdjustment(ba.default_options(linear_solver=2, pcg_tolerance=1e-12, pcg_max_iterations=3000)) as h:
         h.load(q)
-        h.debug_step(1e2)
-        S, dc = h.debug_read(L.DBG_S_DENSE), h.debug_read(L.DBG_STEP_CAM)
+        h.debug_step(1e2)          # the first solve finds out how many rounds it takes ...
+        h.debug_step(1e2)          # ... and the second one enqueues them
+        S, dc, sc = h.debug_read(L.DBG_S_DENSE), h.debug_read(L.DBG_STEP_CAM), h.debug_read(L.DBG_STEP_SCALARS)
     np.testing.assert_allclose(S, ref["S"], rtol=1e-9, atol=1e-11 * np.abs(ref["S"]).max())
-    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-4, atol=1e-6 * np.abs(ref["dc"]).max())
+    assert sc[5] == 0 and 2 <= sc[4] <= 20, sc      # status, PCG rounds: more than the one an exact factor needs, far fewer than block-Jacobi's hundreds
+    np.testing.assert_allclose(dc, ref["dc"], rtol=1e-6, atol=1e-9 * np.abs(ref["dc"]).max())
     with pytest.raises(L.SoslamError):
         with ba.BundleAdjustment(ba.default_options(linear_solver=3)) as h:
             h.load(q)
+
+
+def test_long_chain_with_loop_closures(gpu, oracle_lib):
+    """The global BA after a pose-graph run (/root/reference/src/pose_graph_optimizer.cpp:95, slam.cpp:156): a 500-camera chain
+    with 20 loop-closure points between distant cameras.  Every LM iteration's reduced solve must converge in at most 20 PCG
+    rounds (band factor of the in-band blocks as the preconditioner, closure blocks in the matrix-vector product), and the
+    iterates must be the oracle's (its solver is direct)."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, n_cam=500, n_pt=20000, track_mode=0, track_len=6, spacing=0.5)
+    rng = np.random.default_rng(11)
+    pairs = [(int(a), int(a + rng.integers(100, 300))) for a in rng.integers(1, 200, 20)]
+    q = _with_loop_closures(synth, p, pairs)
+    iters = 8
+    with ba.BundleAdjustment(ba.default_options(linear_solver=2, pcg_tolerance=1e-10)) as h:
+        h.load(q)
+        h.iterate(iters)
+        log = h.iteration_log()
+        cams, pts = h.get_state()
+    rounds = [it.linear_iterations for it in log[1:]]
+    assert max(rounds) <= 20 and max(rounds) >= 2, rounds
+    o = oracle_lib.default_options(max_iterations=iters, check_termination=0, num_threads=min(16, os.cpu_count() or 1))
+    ocams, opts_, osum, olog = oracle_lib.solve(q.obs_cam, q.obs_pt, q.obs_uv, q.poses_cw(), q.points_f64(), q.proj_l, q.proj_r,
+                                                q.cam_fixed, o)
+    assert [it.accepted for it in log] == [e.accepted for e in olog]
+    np.testing.assert_allclose([it.cost for it in log], [e.cost for e in olog], rtol=1e-6)
+    assert np.abs(cams - ocams).max() < ABS_POSE
 
 
 @pytest.mark.parametrize("solver", [2, 3])
