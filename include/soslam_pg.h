@@ -27,6 +27,10 @@ extern "C" {
 #endif
 
 enum { SOSLAM_PG_TERM_ITERATIONS = 0, SOSLAM_PG_TERM_TRIALS = 1, SOSLAM_PG_TERM_FAILURE = 2 };
+/* preconditioner of the PCG that stands in for g2o's LinearSolverEigen (a direct sparse Cholesky,
+ * /root/reference/src/pose_graph_optimizer.cpp:14-18): block-Jacobi, or block-Jacobi plus a coarse space of six rigid-body modes
+ * per aggregate of neighbouring vertices (two-level; AUTO takes it from 256 free vertices on) */
+enum { SOSLAM_PG_PRECOND_AUTO = 0, SOSLAM_PG_PRECOND_BLOCK_JACOBI = 1, SOSLAM_PG_PRECOND_TWO_LEVEL = 2 };
 
 typedef struct soslam_pg_options {
     int32_t max_iterations;      /* 10: optimize(10), /root/reference/src/pose_graph_optimizer.cpp:69 */
@@ -37,7 +41,7 @@ typedef struct soslam_pg_options {
     int32_t pcg_max_iterations;  /* 4000 */
     int32_t verbose;             /* 1 = one line per iteration (setVerbose(true), :21) */
     int32_t device;              /* -1 = current */
-    int32_t reserved;
+    int32_t preconditioner;      /* SOSLAM_PG_PRECOND_*; 0 = AUTO */
     void*   stream;              /* hipStream_t; NULL = own stream */
 } soslam_pg_options;
 

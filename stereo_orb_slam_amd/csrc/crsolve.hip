@@ -710,6 +710,137 @@ __global__ __launch_bounds__(kDense2Threads) void dense2_solve_kernel(const BsrV
     if (tid < 6 * nb) x[tid] = tid < sA ? vx[0][tid] + vb[0][tid] : vx[1][tid - sA] + vb[1][tid - sA];
 }
 
+
+// ---- dense SPD inverse, in place, by block Gauss-Jordan over 60 x 60 tiles ----------------------------------------------------
+// The coarse matrix of the pose graph's two-level preconditioner (pg_solver.hip: ten aggregates of six rigid-body modes per
+// tile, a few hundred to a thousand unknowns) is inverted explicitly, so that every PCG iteration applies it as one small dense
+// product.  A is nb x nb tiles of 60 x 60, row-major with leading dimension 60 nb, symmetric positive definite.  Per pivot
+// tile K:  E = A_KK^-1 (the register-resident sweep of cr_invert);  row: A_Kj <- E A_Kj;  update: A_ij -= A_iK A_Kj (new row,
+// old column);  column: A_iK <- -A_iK E, A_KK <- E.  The column step of pivot K shares a launch with the inversion of pivot
+// K + 1 (they touch different tiles): 3 nb + 1 launches, every one a grid of 64^3 products on the f64 matrix cores.
+constexpr int kTile = 60;
+
+__device__ __forceinline__ void tile_to_image(const double* __restrict__ src, int ld, double* __restrict__ img, bool transpose)
+{
+    // 256 lanes: wave w takes rows w, w + 4, ..; lane = column (coalesced)
+    const int lane = threadIdx.x % 64, wave = threadIdx.x / 64;
+    for (int row = wave; row < kTile; row += 4)
+        if (lane < kTile) {
+            const double v = src[(size_t)row * ld + lane];
+            img[transpose ? lane * kLd + row : row * kLd + lane] = v;
+        }
+}
+
+// C (60 x 60 in global memory) = alpha * (P^T Q) + beta * C for LDS images P, Q (64 rows, zero beyond 60)
+__device__ __forceinline__ void tile_product_store(const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ C, int ld,
+                                                   double alpha, bool accumulate)
+{
+    const int lane = threadIdx.x % 64, wave = threadIdx.x / 64;
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++) {
+        const double4_t t = mfma_ptq_tile(P, Q, 16 * wave, 16 * tj, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * wave + 4 * r + lane / 16, col = 16 * tj + lane % 16;
+            if (row < kTile && col < kTile) {
+                double* dst = C + (size_t)row * ld + col;
+                *dst = accumulate ? *dst + alpha * t[r] : alpha * t[r];
+            }
+        }
+    }
+}
+
+// blockIdx 0: E = A_KK^-1 -> Ebuf (pivot tile K); blockIdx 1..: column step of the PREVIOUS pivot Kp (tile rows i != Kp):
+// A_iKp <- -A_iKp Eprev; the last of them also stores Eprev into A_KpKp.  Kp < 0: no previous pivot; K >= nb: no pivot left.
+__global__ __launch_bounds__(256) void bgj_pivot_kernel(double* __restrict__ A, const int nb, const int K, const int Kp,
+                                                        double* __restrict__ Ebuf, const double* __restrict__ Eprev, double* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double strips[2][4][64];
+    __shared__ double pblk[2][16];
+    const int ld = kTile * nb;
+    const int lane = threadIdx.x % 64, wave = __builtin_amdgcn_readfirstlane(threadIdx.x / 64);
+    const int lr = lane % 16, lk = lane / 16;
+    if (blockIdx.x == 0) {
+        if (K >= nb) return;
+        const double* src = A + ((size_t)K * kTile) * ld + (size_t)K * kTile;
+        double4_t acc[4];
+#pragma unroll
+        for (int tr = 0; tr < 4; tr++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * tr + 4 * r + lk, j = 16 * wave + lr;
+                acc[tr][r] = (i < kTile && j < kTile) ? src[(size_t)i * ld + j] : (i == j ? 1.0 : 0.0);
+            }
+        const bool ok = gj_sweep<kTile / 3>(acc, strips, pblk, wave, lane);
+        if (!ok) status[0] = 1.0;
+        double* X = lds;
+#pragma unroll
+        for (int tr = 0; tr < 4; tr++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) X[(16 * tr + 4 * r + lk) * kLd + 16 * wave + lr] = acc[tr][r];
+        __syncthreads();
+        for (int i = wave; i < kTile; i += 4)
+            if (lane < kTile) Ebuf[i * kTile + lane] = 0.5 * (X[i * kLd + lane] + X[lane * kLd + i]);
+        return;
+    }
+    if (Kp < 0) return;
+    int i = (int)blockIdx.x - 1;
+    if (i >= Kp) i++;                      // tile rows 0 .. nb - 1 without Kp
+    double* B0 = lds;                      // A_iKp^T
+    double* B1 = B0 + kImgRows * kLd;      // Eprev
+    for (int e = threadIdx.x; e < kImgRows * kLd; e += 256) reinterpret_cast<double2*>(lds)[e] = make_double2(0.0, 0.0);
+    __syncthreads();
+    if (i < nb) {
+        double* tile = A + ((size_t)i * kTile) * ld + (size_t)Kp * kTile;
+        tile_to_image(tile, ld, B0, true);
+        tile_to_image(Eprev, kTile, B1, false);
+        __syncthreads();
+        tile_product_store(B0, B1, tile, ld, -1.0, false);
+    } else {
+        // one more workgroup: the pivot tile itself becomes Eprev
+        double* tile = A + ((size_t)Kp * kTile) * ld + (size_t)Kp * kTile;
+        for (int row = wave; row < kTile; row += 4)
+            if (lane < kTile) tile[(size_t)row * ld + lane] = Eprev[row * kTile + lane];
+    }
+}
+
+// row step: A_Kj <- E A_Kj for j != K
+__global__ __launch_bounds__(256) void bgj_row_kernel(double* __restrict__ A, const int nb, const int K, const double* __restrict__ E)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int ld = kTile * nb;
+    int j = (int)blockIdx.x;
+    if (j >= K) j++;
+    double* B0 = lds;                      // E (symmetric: P^T = E)
+    double* B1 = B0 + kImgRows * kLd;      // A_Kj
+    for (int e = threadIdx.x; e < kImgRows * kLd; e += 256) reinterpret_cast<double2*>(lds)[e] = make_double2(0.0, 0.0);
+    __syncthreads();
+    double* tile = A + ((size_t)K * kTile) * ld + (size_t)j * kTile;
+    tile_to_image(E, kTile, B0, false);
+    tile_to_image(tile, ld, B1, false);
+    __syncthreads();
+    tile_product_store(B0, B1, tile, ld, 1.0, false);
+}
+
+// update: A_ij -= A_iK A_Kj for i != K, j != K (A_Kj: the new row, A_iK: the old column)
+__global__ __launch_bounds__(256) void bgj_update_kernel(double* __restrict__ A, const int nb, const int K)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int ld = kTile * nb;
+    int i = (int)blockIdx.y, j = (int)blockIdx.x;
+    if (i >= K) i++;
+    if (j >= K) j++;
+    double* B0 = lds;                      // A_iK^T
+    double* B1 = B0 + kImgRows * kLd;      // A_Kj
+    for (int e = threadIdx.x; e < kImgRows * kLd; e += 256) reinterpret_cast<double2*>(lds)[e] = make_double2(0.0, 0.0);
+    __syncthreads();
+    tile_to_image(A + ((size_t)i * kTile) * ld + (size_t)K * kTile, ld, B0, true);
+    tile_to_image(A + ((size_t)K * kTile) * ld + (size_t)j * kTile, ld, B1, false);
+    __syncthreads();
+    tile_product_store(B0, B1, A + ((size_t)i * kTile) * ld + (size_t)j * kTile, ld, -1.0, true);
+}
+
 // ---- solve phase: every step is a matrix-vector product with a stored sb x sb operator ------------------------
 // w holds the right-hand side on entry (padded to m*sb), the solution on exit.
 
@@ -1294,6 +1425,34 @@ void launch_cr_solve(hipStream_t s, uint32_t n_rows, int bw, double* ws, const d
         h /= 4; lev -= 2;   // the pair (2h, h) = levels lev + 1, lev
         hipLaunchKernelGGL(cr_bwd2_kernel, dim3(count_odd(v.m, h)), dim3(kCrSolveThreads), 0, s, v, h, own[lev].p, own[lev].n,
                            own[lev + 1].p, xs, x, n, done_flag);
+    }
+}
+
+// A (60 nb)^2, in place; ebuf: 2 x 3600 f64 of scratch; status[0] = 1 when a pivot tile was not positive definite
+void launch_dense_spd_inverse60(hipStream_t s, double* A, int nb, double* ebuf, double* status)
+{
+    if (nb < 1) return;
+    const size_t lds2 = sizeof(double) * 2 * kImgRows * kLd;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev >= 0 && dev < 64 ? dev : 0;
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bgj_pivot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bgj_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bgj_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        attr_set[dev] = true;
+    }
+    double* E[2] = {ebuf, ebuf + kTile * kTile};
+    for (int K = 0; K <= nb; K++) {
+        // inversion of pivot K beside the column step of pivot K - 1 (nb - 1 tiles and the pivot tile itself)
+        const int Kp = K - 1;
+        hipLaunchKernelGGL(bgj_pivot_kernel, dim3(Kp >= 0 ? 1 + nb : 1), dim3(256), lds2, s, A, nb, K, Kp, E[K & 1], E[(K & 1) ^ 1], status);
+        if (K == nb) break;
+        if (nb > 1) {
+            hipLaunchKernelGGL(bgj_row_kernel, dim3(nb - 1), dim3(256), lds2, s, A, nb, K, E[K & 1]);
+            hipLaunchKernelGGL(bgj_update_kernel, dim3(nb - 1, nb - 1), dim3(256), lds2, s, A, nb, K);
+        }
     }
 }
 

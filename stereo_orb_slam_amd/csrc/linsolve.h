@@ -48,6 +48,9 @@ constexpr int kDenseSmallRowsMax = 22;   // 132 unknowns: 132 x 133 f64 = 140 KB
 bool dense_small_fits(uint32_t n_rows);
 // <= 20 block rows: two-block elimination on the matrix cores by one workgroup (crsolve.hip), same interface
 bool dense2_fits(uint32_t n_rows);
+// dense symmetric positive definite inverse in place by block Gauss-Jordan over 60 x 60 tiles (crsolve.hip): A is (60 nb)^2
+// row-major, ebuf 2 x 3600 f64 of scratch, status[0] = 1 when a pivot tile was not positive definite
+void launch_dense_spd_inverse60(hipStream_t s, double* A, int nb, double* ebuf, double* status);
 void launch_dense2_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
                          const double* b, double* x, double* scal);
 void launch_dense_small_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
@@ -125,5 +128,23 @@ size_t pcg_multi_work_count(uint32_t n_rows);   // f64 of caller-provided work s
 // resid (required: it is the iteration's residual vector) receives the final b - (A + shift I) x.
 int pcg_multi_solve(hipStream_t s, const BsrView& A, double shift, const double* b, double* x, double* resid,
                     double* work, double tol, int max_iter, int chunk, double* rel_resid);
+
+}  // namespace soslam
+
+namespace soslam {
+
+// ---- two-level PCG (pcg_multi.hip): block-Jacobi + an aggregation coarse space with an explicit coarse inverse ---------------
+struct TwoLevelView {
+    uint32_t n_agg;              // aggregates (one workgroup each; at most 42 block rows, contiguous)
+    uint32_t ncp;                // coarse dimension padded to a multiple of 60 (launch_dense_spd_inverse60), <= 1260
+    const uint32_t* agg_ptr;     // [n_agg + 1] first block row of every aggregate
+    const double* P;             // [n_rows][36] row-major: the block row's increment per coarse unknown of its aggregate
+    const double* Ainv;          // [ncp * ncp] (P^T (A + shift I) P)^-1, written by pcg2_solve
+    double* rc;                  // [ncp] P^T r (entries from 6 n_agg on stay zero)
+};
+size_t pcg2_work_count(uint32_t n_rows, uint32_t n_agg);
+// as pcg_multi_solve; Ac0 = P^T A P ([ncp * ncp], without the shift), G = P^T P per aggregate ([n_agg][36]), ebuf 2 x 3600 f64
+int pcg2_solve(hipStream_t s, const BsrView& A, double shift, const double* b, double* x, double* resid, double* work, const TwoLevelView& tl,
+               const double* Ac0, const double* G, double* ebuf, double tol, int max_iter, int chunk, double* rel_resid);
 
 }  // namespace soslam

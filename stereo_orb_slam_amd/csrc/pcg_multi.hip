@@ -274,6 +274,202 @@ __global__ __launch_bounds__(kThreads) void pcgm_update_kernel(const uint32_t n,
     }
 }
 
+
+// ---- two-level PCG: block-Jacobi + an aggregation coarse space ------------------------------------------------------------------
+// For the pose graph (pg_solver.hip): the graph's Hessian has smooth near-null modes - rigid motions of whole regions - that
+// block-Jacobi sees one vertex at a time (850 iterations per solve on BASELINE.json configs[4]).  The additive two-level
+// preconditioner   z = D^-1 r + P (P^T (A + shift I) P)^-1 P^T r   adds a coarse space of six rigid-body modes per aggregate
+// of at most 42 neighbouring vertices (P_i = the vertex's local increment under a rigid motion of its aggregate; the
+// coarse matrix is inverted explicitly by launch_dense_spd_inverse60, so applying it is one small dense product).  A CPU
+// prototype on configs[4] gave 368 iterations for block-Jacobi, 46 - 75 for this (aggregates of 25 - 100 vertices).
+// One workgroup per aggregate (the block rows of an aggregate are contiguous): three kernels per iteration -
+//   matvec   as pcgm_matvec;   update   alpha, x, r, the fine part D^-1 r and this aggregate's P^T r;
+//   coarse   y = (row block of the coarse inverse) . (P^T r of all aggregates), z = D^-1 r + P y, partial r.z.
+struct Pcg2Bufs {
+    double *p[2], *z, *q, *minv, *part_pq, *part_rz, *part_rr, *state;
+    uint32_t n_wg;
+};
+
+__global__ __launch_bounds__(kThreads) void pcg2_init_kernel(const BsrView A, const double shift, const double* __restrict__ b,
+                                                             double* __restrict__ x, double* __restrict__ r, const Pcg2Bufs w,
+                                                             const TwoLevelView tl)
+{
+    __shared__ double red[4];
+    __shared__ double rloc[kRowsPerWg * 6], yl[kRowsPerWg * 6];
+    const uint32_t r0 = tl.agg_ptr[blockIdx.x], nr = tl.agg_ptr[blockIdx.x + 1] - r0;
+    const int t = threadIdx.x;
+    const uint32_t i = r0 * 6 + t;
+    const bool act = t < (int)(nr * 6);
+    if (t < (int)nr) {
+        const uint32_t f = r0 + t;
+        if (!spd6_inverse_shift(A.blocks + 36 * (size_t)A.diag_block[f], shift, w.minv + 36 * (size_t)f)) w.state[ST_BREAKDOWN] = 1.0;
+    }
+    double bi = 0.0;
+    if (act) { bi = b[i]; x[i] = 0.0; r[i] = bi; rloc[t] = bi; }
+    __syncthreads();
+    if (act) {
+        const double* M = w.minv + 36 * (size_t)(i / 6) + 6 * (i % 6);
+        const double* rv = rloc + (t / 6) * 6;
+        w.z[i] = M[0] * rv[0] + M[1] * rv[1] + M[2] * rv[2] + M[3] * rv[3] + M[4] * rv[4] + M[5] * rv[5];
+        // (P_v^T r_v)[a], a = t % 6
+        const double* Pv = tl.P + 36 * (size_t)(i / 6);
+        const int a = t % 6;
+        yl[t] = Pv[a] * rv[0] + Pv[6 + a] * rv[1] + Pv[12 + a] * rv[2] + Pv[18 + a] * rv[3] + Pv[24 + a] * rv[4] + Pv[30 + a] * rv[5];
+    }
+    __syncthreads();
+    if (t < 6) {
+        double s = 0.0;
+        for (uint32_t v = 0; v < nr; v++) s += yl[v * 6 + t];
+        tl.rc[blockIdx.x * 6 + t] = s;
+    }
+    const double bb = block_sum256(bi * bi, red);
+    if (t == 0) {
+        w.part_rr[blockIdx.x] = bb;
+        if (blockIdx.x == 0) w.state[ST_ITERS] = 0.0;
+    }
+}
+
+// INIT: behind pcg2_init (writes p[0] = z and the parity-0 r.z); else behind the update of iteration `parity`
+template <bool INIT>
+__global__ __launch_bounds__(kThreads) void pcg2_coarse_kernel(const double* __restrict__ r, const Pcg2Bufs w, const TwoLevelView tl,
+                                                               const int parity, const double tol)
+{
+    __shared__ double red[4];
+    __shared__ double rcl[1280];          // P^T r of every aggregate (ncp <= 1260)
+    __shared__ double part[6][40];
+    __shared__ double y[6];
+    if (!INIT) {
+        if (w.state[ST_DONE] != 0.0 || w.state[ST_BREAKDOWN] != 0.0) return;
+        const double rr_old = coop_sum(w.part_rr + parity * w.n_wg, w.n_wg, red);
+        if (!(rr_old > tol * tol * w.state[ST_BB])) return;   // as the update of this iteration decided
+        __syncthreads();
+    }
+    const int t = threadIdx.x;
+    const uint32_t r0 = tl.agg_ptr[blockIdx.x], nr = tl.agg_ptr[blockIdx.x + 1] - r0;
+    for (uint32_t j = t; j < tl.ncp; j += kThreads) rcl[j] = tl.rc[j];
+    __syncthreads();
+    if (t < 240) {
+        const int a = t / 40, s = t % 40;
+        const double* row = tl.Ainv + (size_t)(blockIdx.x * 6 + a) * tl.ncp;
+        double sum = 0.0;
+        for (uint32_t j = s; j < tl.ncp; j += 40) sum += row[j] * rcl[j];
+        part[a][s] = sum;
+    }
+    __syncthreads();
+    if (t < 6) {
+        double sum = 0.0;
+#pragma unroll
+        for (int s = 0; s < 40; s++) sum += part[t][s];
+        y[t] = sum;
+    }
+    __syncthreads();
+    const uint32_t i = r0 * 6 + t;
+    double rz = 0.0;
+    if (t < (int)(nr * 6)) {
+        const double* Pv = tl.P + 36 * (size_t)(i / 6) + 6 * (i % 6);
+        const double zi = w.z[i] + (Pv[0] * y[0] + Pv[1] * y[1] + Pv[2] * y[2] + Pv[3] * y[3] + Pv[4] * y[4] + Pv[5] * y[5]);
+        w.z[i] = zi;
+        if (INIT) w.p[0][i] = zi;
+        rz = r[i] * zi;
+    }
+    rz = block_sum256(rz, red);
+    if (t == 0) w.part_rz[(INIT ? 0 : (parity ^ 1)) * w.n_wg + blockIdx.x] = rz;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kThreads) void pcg2_matvec_kernel(const BsrView A, const double shift, const Pcg2Bufs w, const TwoLevelView tl,
+                                                               const int parity, const double tol)
+{
+    __shared__ double red[4];
+    __shared__ double red3[3][4];
+    if (w.state[ST_DONE] != 0.0) return;
+    double rr, rz_new, rz_old;
+    coop_sum3(w.part_rr + parity * w.n_wg, w.part_rz + parity * w.n_wg, w.part_rz + (parity ^ 1) * w.n_wg, w.n_wg, red3, rr, rz_new, rz_old);
+    if (!(rr > tol * tol * w.state[ST_BB]) || w.state[ST_BREAKDOWN] != 0.0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) w.state[ST_DONE] = 1.0;
+        return;
+    }
+    const double beta = FIRST ? 0.0 : rz_new / rz_old;
+    const double* p_old = w.p[FIRST ? 0 : parity ^ 1];
+    const uint32_t r0 = tl.agg_ptr[blockIdx.x], nr = tl.agg_ptr[blockIdx.x + 1] - r0;
+    const int t = threadIdx.x;
+    const uint32_t i = r0 * 6 + t;
+    double pq = 0.0;
+    if (t < (int)(nr * 6)) {
+        const double pi = FIRST ? p_old[i] : w.z[i] + beta * p_old[i];
+        if (!FIRST) w.p[parity][i] = pi;
+        const double qi = bsr_row_dot_dir<FIRST>(A, i, w.z, p_old, beta) + shift * pi;
+        w.q[i] = qi;
+        pq = pi * qi;
+    }
+    pq = block_sum256(pq, red);
+    if (t == 0) w.part_pq[blockIdx.x] = pq;
+}
+
+__global__ __launch_bounds__(kThreads) void pcg2_update_kernel(double* __restrict__ x, double* __restrict__ r, const Pcg2Bufs w,
+                                                               const TwoLevelView tl, const int parity, const double tol)
+{
+    __shared__ double red[4];
+    __shared__ double red3[3][4];
+    __shared__ double rloc[kRowsPerWg * 6], yl[kRowsPerWg * 6];
+    if (w.state[ST_DONE] != 0.0) return;
+    double rr_old, pq, rz;
+    coop_sum3(w.part_rr + parity * w.n_wg, w.part_pq, w.part_rz + parity * w.n_wg, w.n_wg, red3, rr_old, pq, rz);
+    if (!(rr_old > tol * tol * w.state[ST_BB]) || w.state[ST_BREAKDOWN] != 0.0) return;
+    const int t = threadIdx.x;
+    if (!(pq > 0.0)) {
+        if (t == 0 && blockIdx.x == 0) w.state[ST_BREAKDOWN] = 2.0;
+        return;
+    }
+    const double alpha = rz / pq;
+    const uint32_t r0 = tl.agg_ptr[blockIdx.x], nr = tl.agg_ptr[blockIdx.x + 1] - r0;
+    const uint32_t i = r0 * 6 + t;
+    const bool act = t < (int)(nr * 6);
+    double ri = 0.0;
+    if (act) {
+        x[i] += alpha * w.p[parity][i];
+        ri = r[i] - alpha * w.q[i];
+        r[i] = ri;
+        rloc[t] = ri;
+    }
+    __syncthreads();
+    if (act) {
+        const double* M = w.minv + 36 * (size_t)(i / 6) + 6 * (i % 6);
+        const double* rv = rloc + (t / 6) * 6;
+        w.z[i] = M[0] * rv[0] + M[1] * rv[1] + M[2] * rv[2] + M[3] * rv[3] + M[4] * rv[4] + M[5] * rv[5];   // the fine part; pcg2_coarse adds P y
+        const double* Pv = tl.P + 36 * (size_t)(i / 6);
+        const int a = t % 6;
+        yl[t] = Pv[a] * rv[0] + Pv[6 + a] * rv[1] + Pv[12 + a] * rv[2] + Pv[18 + a] * rv[3] + Pv[24 + a] * rv[4] + Pv[30 + a] * rv[5];
+    }
+    __syncthreads();
+    if (t < 6) {
+        double s = 0.0;
+        for (uint32_t v = 0; v < nr; v++) s += yl[v * 6 + t];
+        tl.rc[blockIdx.x * 6 + t] = s;
+    }
+    const double rr = block_sum256(ri * ri, red);
+    if (t == 0) {
+        w.part_rr[(parity ^ 1) * w.n_wg + blockIdx.x] = rr;
+        if (blockIdx.x == 0) w.state[ST_ITERS] += 1.0;
+    }
+}
+
+// Ainv <- Ac0 + shift * blockdiag(G) on the coarse unknowns, the identity on the padding; the caller inverts it in place
+__global__ __launch_bounds__(256) void pcg2_coarse_matrix_kernel(const double* __restrict__ Ac0, const double* __restrict__ G, const double shift,
+                                                                 const uint32_t nc, const uint32_t ncp, double* __restrict__ out)
+{
+    const uint32_t row = blockIdx.x;
+    for (uint32_t col = threadIdx.x; col < ncp; col += 256) {
+        double v;
+        if (row >= nc || col >= nc) v = row == col ? 1.0 : 0.0;
+        else {
+            v = Ac0[(size_t)row * ncp + col];
+            if (row / 6 == col / 6) v += shift * G[36 * (size_t)(row / 6) + (row % 6) * 6 + col % 6];
+        }
+        out[(size_t)row * ncp + col] = v;
+    }
+}
+
 }  // namespace
 
 size_t pcg_multi_work_count(uint32_t n_rows)
@@ -320,6 +516,69 @@ int pcg_multi_solve(hipStream_t s, const BsrView& A, double shift, const double*
         if (host_state[ST_BREAKDOWN] != 0.0) return -1;
         const int done = (int)host_state[ST_ITERS];
         const int par = done & 1;   // parity after `done` updates
+        rr = 0.0;
+        for (uint32_t i = 0; i < n_wg; i++) rr += rrp[(size_t)par * n_wg + i];
+        if (!(rr > tol * tol * host_state[ST_BB]) || done < launched) {
+            if (rel_resid) *rel_resid = host_state[ST_BB] > 0 ? std::sqrt(rr / host_state[ST_BB]) : 0.0;
+            return done;
+        }
+    }
+    if (rel_resid) *rel_resid = host_state[ST_BB] > 0 ? std::sqrt(rr / host_state[ST_BB]) : 0.0;
+    return (int)host_state[ST_ITERS];
+}
+
+}  // namespace soslam
+
+namespace soslam {
+
+size_t pcg2_work_count(uint32_t n_rows, uint32_t n_agg)
+{
+    const size_t n = (size_t)n_rows * 6;
+    return 4 * n + 36 * (size_t)n_rows + 5 * (size_t)n_agg + ST_COUNT + 16;
+}
+
+int pcg2_solve(hipStream_t s, const BsrView& A, double shift, const double* b, double* x, double* resid, double* work, const TwoLevelView& tl,
+               const double* Ac0, const double* G, double* ebuf, double tol, int max_iter, int chunk, double* rel_resid)
+{
+    if (rel_resid) *rel_resid = 0.0;
+    if (!A.n_rows) return 0;
+    if (!resid || tl.ncp > 1260 || tl.ncp % 60 != 0) return -2;
+    const uint32_t n = A.n_rows * 6, n_wg = tl.n_agg;
+    Pcg2Bufs w;
+    w.n_wg = n_wg;
+    w.p[0] = work; w.p[1] = w.p[0] + n; w.z = w.p[1] + n; w.q = w.z + n; w.minv = w.q + n;
+    w.part_pq = w.minv + 36 * (size_t)A.n_rows;
+    w.part_rz = w.part_pq + n_wg;
+    w.part_rr = w.part_rz + 2 * (size_t)n_wg;
+    w.state = w.part_rr + 2 * (size_t)n_wg;
+    double* r = resid;
+    (void)hipMemsetAsync(w.state, 0, sizeof(double) * ST_COUNT, s);
+    // the coarse operator for this shift: (P^T A P + shift P^T P)^-1, explicit
+    hipLaunchKernelGGL(pcg2_coarse_matrix_kernel, dim3(tl.ncp), dim3(256), 0, s, Ac0, G, shift, tl.n_agg * 6, tl.ncp, const_cast<double*>(tl.Ainv));
+    launch_dense_spd_inverse60(s, const_cast<double*>(tl.Ainv), (int)(tl.ncp / 60), ebuf, w.state + ST_BREAKDOWN);
+    hipLaunchKernelGGL(pcg2_init_kernel, dim3(n_wg), dim3(kThreads), 0, s, A, shift, b, x, r, w, tl);
+    hipLaunchKernelGGL(pcgm_bb_kernel, dim3(1), dim3(64), 0, s, PcgBufs{{w.p[0], w.p[1]}, w.z, w.q, w.minv, w.part_pq, w.part_rz, w.part_rr, w.state, w.n_wg});
+    hipLaunchKernelGGL(pcg2_coarse_kernel<true>, dim3(n_wg), dim3(kThreads), 0, s, r, w, tl, 0, tol);
+    int parity = 0, launched = 0;
+    double host_state[ST_COUNT] = {0, 0, 0, 0};
+    double rr = 0.0;
+    while (launched < max_iter) {
+        const int todo = std::min(chunk, max_iter - launched);
+        for (int k = 0; k < todo; k++) {
+            if (launched + k == 0) hipLaunchKernelGGL(pcg2_matvec_kernel<true>, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, tl, parity, tol);
+            else hipLaunchKernelGGL(pcg2_matvec_kernel<false>, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, tl, parity, tol);
+            hipLaunchKernelGGL(pcg2_update_kernel, dim3(n_wg), dim3(kThreads), 0, s, x, r, w, tl, parity, tol);
+            hipLaunchKernelGGL(pcg2_coarse_kernel<false>, dim3(n_wg), dim3(kThreads), 0, s, r, w, tl, parity, tol);
+            parity ^= 1;
+        }
+        launched += todo;
+        std::vector<double> rrp(2 * (size_t)n_wg);
+        if (hipMemcpyAsync(host_state, w.state, sizeof host_state, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipMemcpyAsync(rrp.data(), w.part_rr, sizeof(double) * rrp.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        if (host_state[ST_BREAKDOWN] != 0.0) return -1;
+        const int done = (int)host_state[ST_ITERS];
+        const int par = done & 1;
         rr = 0.0;
         for (uint32_t i = 0; i < n_wg; i++) rr += rrp[(size_t)par * n_wg + i];
         if (!(rr > tol * tol * host_state[ST_BB]) || done < launched) {

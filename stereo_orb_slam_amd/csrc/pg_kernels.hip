@@ -324,6 +324,91 @@ __global__ __launch_bounds__(256) void pg_update_kernel(uint32_t n_vertex, const
     if (threadIdx.x == 0) scale_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+
+// ---- coarse space of the two-level preconditioner (pcg_multi.hip: pcg2_solve) ---------------------------------------------------
+// P_v (6 x 6, row-major): the increment [dt, dq.xyz] of vertex v (g2o's X <- X * fromVectorMQT(increment), a motion in the
+// vertex's own frame) under a small rigid motion (v, w) of its whole aggregate about the aggregate's reference position:
+//   world motion x -> x + w x (x - c) + v   =>   dt = R^T (v + w x (t - c)),  dq = R^T w / 2.
+__global__ __launch_bounds__(256) void pg_coarse_basis_kernel(const uint32_t n_free, const uint32_t* __restrict__ free_vertex,
+                                                              const uint32_t* __restrict__ row_agg, const uint32_t* __restrict__ agg_ref,
+                                                              const double* __restrict__ est, double* __restrict__ P)
+{
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_free) return;
+    const double* x = est + 7 * (size_t)free_vertex[f];
+    const double* c = est + 7 * (size_t)agg_ref[row_agg[f]];
+    double R[9];
+    qrot(qnormalized(Quat{x[3], x[4], x[5], x[6]}), R);
+    const double t[3] = {x[0] - c[0], x[1] - c[1], x[2] - c[2]};
+    // [t]x
+    const double tx[9] = {0.0, -t[2], t[1], t[2], 0.0, -t[0], -t[1], t[0], 0.0};
+    double* Pv = P + 36 * (size_t)f;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const double rt = R[b * 3 + a];                                    // R^T[a][b]
+            double m = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) m += R[k * 3 + a] * tx[k * 3 + b];     // (R^T [t]x)[a][b]
+            Pv[a * 6 + b] = rt;
+            Pv[a * 6 + 3 + b] = -m;
+            Pv[(3 + a) * 6 + b] = 0.0;
+            Pv[(3 + a) * 6 + 3 + b] = 0.5 * rt;
+        }
+}
+
+// G_I = sum over the aggregate's vertices of P_v^T P_v (the shift's share of the coarse matrix); one wave per aggregate
+__global__ __launch_bounds__(64) void pg_coarse_gram_kernel(const uint32_t* __restrict__ agg_ptr, const double* __restrict__ P, double* __restrict__ G)
+{
+    const uint32_t I = blockIdx.x;
+    const int e = threadIdx.x;
+    if (e >= 36) return;
+    const int a = e / 6, b = e % 6;
+    double s = 0.0;
+    for (uint32_t f = agg_ptr[I]; f < agg_ptr[I + 1]; f++) {
+        const double* Pv = P + 36 * (size_t)f;
+#pragma unroll
+        for (int c = 0; c < 6; c++) s += Pv[c * 6 + a] * Pv[c * 6 + b];
+    }
+    G[36 * (size_t)I + e] = s;
+}
+
+// one coarse block (I, J) of P^T H P: the sum over its fine blocks, in list order (entry = 2 * block + swap; swap: the stored
+// block is H(i, j) with i in J and j in I, so its transpose is what couples I to J).  One wave per coarse block.
+__global__ __launch_bounds__(64) void pg_coarse_assemble_kernel(const uint32_t* __restrict__ cb_ptr, const uint32_t* __restrict__ cb_ent,
+                                                                const uint32_t* __restrict__ cb_I, const uint32_t* __restrict__ cb_J,
+                                                                const uint32_t* __restrict__ blk_row, const uint32_t* __restrict__ blk_col,
+                                                                const double* __restrict__ H, const double* __restrict__ P, const uint32_t ncp,
+                                                                double* __restrict__ Ac0)
+{
+    __shared__ double T[36];
+    const uint32_t cb = blockIdx.x;
+    const int e = threadIdx.x, a = e / 6, b = e % 6;
+    double acc = 0.0;
+    for (uint32_t q = cb_ptr[cb]; q < cb_ptr[cb + 1]; q++) {
+        const uint32_t blk = cb_ent[q] >> 1, swap = cb_ent[q] & 1;
+        const uint32_t i = blk_row[blk], j = blk_col[blk];
+        const double* Hb = H + 36 * (size_t)blk;
+        const double* L = P + 36 * (size_t)(swap ? j : i);
+        const double* Rr = P + 36 * (size_t)(swap ? i : j);
+        // T = Hm Rr with Hm = Hb or Hb^T
+        if (e < 36) {
+            double t = 0.0;
+#pragma unroll
+            for (int d = 0; d < 6; d++) t += (swap ? Hb[d * 6 + a] : Hb[a * 6 + d]) * Rr[d * 6 + b];
+            T[e] = t;
+        }
+        __syncthreads();
+        if (e < 36) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc += L[c * 6 + a] * T[c * 6 + b];
+        }
+        __syncthreads();
+    }
+    if (e < 36) Ac0[(size_t)(6 * cb_I[cb] + a) * ncp + 6 * cb_J[cb] + b] = acc;
+}
+
 }  // namespace
 
 void launch_pg_linearize(hipStream_t s, uint32_t n_edge, const double* est, const uint32_t* ef, const uint32_t* et,
@@ -361,6 +446,18 @@ void launch_pg_update(hipStream_t s, uint32_t n_vertex, const double* est, const
     if (!n_vertex) return;
     hipLaunchKernelGGL(pg_update_kernel, dim3((n_vertex + 255) / 256), dim3(256), 0, s, n_vertex, est, free_idx, x, b, lambda, cand,
                        scale_part);
+}
+
+void launch_pg_coarse_setup(hipStream_t s, uint32_t n_free, uint32_t n_agg, const uint32_t* free_vertex, const uint32_t* row_agg,
+                            const uint32_t* agg_ref, const uint32_t* agg_ptr, const double* est, uint32_t n_cb, const uint32_t* cb_ptr,
+                            const uint32_t* cb_ent, const uint32_t* cb_I, const uint32_t* cb_J, const uint32_t* blk_row, const uint32_t* blk_col,
+                            const double* H, uint32_t ncp, double* P, double* G, double* Ac0)
+{
+    if (!n_free || !n_agg) return;
+    hipLaunchKernelGGL(pg_coarse_basis_kernel, dim3((n_free + 255) / 256), dim3(256), 0, s, n_free, free_vertex, row_agg, agg_ref, est, P);
+    hipLaunchKernelGGL(pg_coarse_gram_kernel, dim3(n_agg), dim3(64), 0, s, agg_ptr, P, G);
+    (void)hipMemsetAsync(Ac0, 0, sizeof(double) * (size_t)ncp * ncp, s);
+    if (n_cb) hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3(n_cb), dim3(64), 0, s, cb_ptr, cb_ent, cb_I, cb_J, blk_row, blk_col, H, P, ncp, Ac0);
 }
 
 }  // namespace soslam

@@ -34,6 +34,11 @@ struct soslam_pg {
     DevBuf<uint8_t> ent_trans;
     DevBuf<int32_t> free_idx, diag_block;
     DevBuf<PgEdgeBlocks> eb;
+    // two-level preconditioner (pcg2_solve): aggregates of neighbouring free vertices, six rigid-body modes each
+    bool two_level = false;
+    uint32_t n_agg = 0, ncp = 0, n_cb = 0;
+    DevBuf<uint32_t> agg_ptr, row_agg, agg_ref, free_vertex, cb_ptr, cb_ent, cb_I, cb_J;
+    DevBuf<double> cP, cG, cAc0, cAinv, cebuf, crc;
     int cur = 0;
     double setup_seconds = 0.0;
     std::vector<soslam_pg_iteration> log;
@@ -75,6 +80,70 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     for (uint32_t v = 0; v < n_vertex; v++)
         if (!(fixed && fixed[v])) h->h_free[v] = (int32_t)nf++;
     h->n_free = nf;
+    // Aggregates for the two-level preconditioner: greedy breadth-first growth over the graph of free vertices, at most
+    // kAggMax vertices each (one workgroup of pcg2_solve per aggregate), compact in the graph whatever the vertex numbering
+    // (a lawn-mower path, a chain with loop closures).  The free indices are then renumbered aggregate by aggregate, so that
+    // an aggregate is a contiguous range of block rows of H.
+    constexpr uint32_t kAggMax = 40;
+    const int pre = h->opt.preconditioner;
+    h->two_level = nf > 0 && (pre == SOSLAM_PG_PRECOND_TWO_LEVEL || (pre == SOSLAM_PG_PRECOND_AUTO && nf >= 256)) && (nf + kAggMax - 1) / kAggMax * 6 <= 1200;
+    std::vector<uint32_t> agg_ptr, row_agg, agg_ref, free_vertex(nf);
+    if (h->two_level) {
+        std::vector<std::vector<uint32_t>> adj(n_vertex);
+        for (uint32_t k = 0; k < n_edge; k++)
+            if (h->h_free[ef[k]] >= 0 && h->h_free[et[k]] >= 0) { adj[ef[k]].push_back(et[k]); adj[et[k]].push_back(ef[k]); }
+        // aggregate sizes: as even as the cap allows (a count of ceil(nf / kAggMax) aggregates, sizes within one of each other
+        // would need a partitioner; breadth-first growth to the target size, leftovers joined to a neighbouring aggregate or kept)
+        const uint32_t target = kAggMax;
+        std::vector<int32_t> agg_of(n_vertex, -1);
+        std::vector<std::vector<uint32_t>> members;
+        std::vector<uint32_t> queue;
+        for (uint32_t seed = 0; seed < n_vertex; seed++) {
+            if (h->h_free[seed] < 0 || agg_of[seed] >= 0) continue;
+            const int32_t id = (int32_t)members.size();
+            members.emplace_back();
+            queue.clear();
+            queue.push_back(seed);
+            agg_of[seed] = id;
+            for (size_t qi = 0; qi < queue.size() && members.back().size() < target; qi++) {
+                const uint32_t v = queue[qi];
+                members.back().push_back(v);
+                for (uint32_t u : adj[v])
+                    if (agg_of[u] < 0 && queue.size() < target) { agg_of[u] = id; queue.push_back(u); }
+            }
+            // vertices claimed for the queue but not reached (the size cap came first) are released
+            for (size_t qi = members.back().size(); qi < queue.size(); qi++) agg_of[queue[qi]] = -1;
+            for (uint32_t v : members.back()) agg_of[v] = id;
+        }
+        // small leftovers (enclosed by full aggregates) join a neighbouring aggregate that still has room
+        for (size_t a = 0; a < members.size(); a++) {
+            if (members[a].empty() || members[a].size() > kAggMax / 4) continue;
+            int32_t best = -1;
+            for (uint32_t v : members[a])
+                for (uint32_t u : adj[v]) {
+                    const int32_t b = agg_of[u];
+                    if (b >= 0 && b != (int32_t)a && members[(size_t)b].size() + members[a].size() <= kAggMax &&
+                        (best < 0 || members[(size_t)b].size() < members[(size_t)best].size())) best = b;
+                }
+            if (best >= 0) {
+                for (uint32_t v : members[a]) { agg_of[v] = best; members[(size_t)best].push_back(v); }
+                members[a].clear();
+            }
+        }
+        uint32_t next = 0;
+        agg_ptr.push_back(0);
+        for (auto& m : members) {
+            if (m.empty()) continue;
+            std::sort(m.begin(), m.end());
+            agg_ref.push_back(m.front());
+            for (uint32_t v : m) { h->h_free[v] = (int32_t)next; free_vertex[next] = v; row_agg.push_back((uint32_t)agg_ptr.size() - 1); next++; }
+            agg_ptr.push_back(next);
+        }
+        h->n_agg = (uint32_t)agg_ptr.size() - 1;
+        h->ncp = (h->n_agg * 6 + 59) / 60 * 60;
+    } else {
+        h->n_agg = 0; h->ncp = 0;
+    }
 
     // upper block pattern: diagonal + one block per connected pair of free vertices
     std::vector<std::vector<uint32_t>> rows(nf);
@@ -103,6 +172,28 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
         auto it = std::lower_bound(r.begin(), r.end(), j);
         return (int32_t)(row_first[i] + (uint32_t)(it - r.begin()));
     };
+    std::vector<uint32_t> cb_ptr, cb_ent, cb_I, cb_J;
+    if (h->two_level) {
+        // non-empty coarse blocks (ordered aggregate pairs) and the fine blocks that feed them, in block order
+        std::vector<std::pair<uint64_t, uint32_t>> items;   // (I * n_agg + J, 2 * block + swap)
+        items.reserve((size_t)h->n_blocks * 2);
+        for (uint32_t blk = 0; blk < h->n_blocks; blk++) {
+            const uint64_t I = row_agg[h->h_blk_row[blk]], J = row_agg[h->h_blk_col[blk]];
+            items.push_back({I * h->n_agg + J, 2 * blk});
+            if (h->h_blk_row[blk] != h->h_blk_col[blk]) items.push_back({J * h->n_agg + I, 2 * blk + 1});
+        }
+        std::sort(items.begin(), items.end());
+        for (size_t q = 0; q < items.size(); q++) {
+            if (q == 0 || items[q].first != items[q - 1].first) {
+                cb_ptr.push_back((uint32_t)q);
+                cb_I.push_back((uint32_t)(items[q].first / h->n_agg));
+                cb_J.push_back((uint32_t)(items[q].first % h->n_agg));
+            }
+            cb_ent.push_back(items[q].second);
+        }
+        cb_ptr.push_back((uint32_t)items.size());
+        h->n_cb = (uint32_t)cb_I.size();
+    }
     std::vector<PgEdgeBlocks> eb(n_edge);
     for (uint32_t k = 0; k < n_edge; k++) {
         const int32_t a = h->h_free[ef[k]], b = h->h_free[et[k]];
@@ -173,7 +264,24 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     SOSLAM_CHECK(h->x.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->x.zero(s));
     SOSLAM_CHECK(h->resid.alloc((size_t)nf * 6));
-    SOSLAM_CHECK(h->work.alloc(pcg_multi_work_count(nf)));
+    SOSLAM_CHECK(h->work.alloc(std::max(pcg_multi_work_count(nf), pcg2_work_count(nf, h->n_agg))));
+    if (h->two_level) {
+        SOSLAM_CHECK(h->agg_ptr.upload(agg_ptr, s));
+        SOSLAM_CHECK(h->row_agg.upload(row_agg, s));
+        SOSLAM_CHECK(h->agg_ref.upload(agg_ref, s));
+        SOSLAM_CHECK(h->free_vertex.upload(free_vertex, s));
+        SOSLAM_CHECK(h->cb_ptr.upload(cb_ptr, s));
+        SOSLAM_CHECK(h->cb_ent.upload(cb_ent, s));
+        SOSLAM_CHECK(h->cb_I.upload(cb_I, s));
+        SOSLAM_CHECK(h->cb_J.upload(cb_J, s));
+        SOSLAM_CHECK(h->cP.alloc((size_t)nf * 36));
+        SOSLAM_CHECK(h->cG.alloc((size_t)h->n_agg * 36));
+        SOSLAM_CHECK(h->cAc0.alloc((size_t)h->ncp * h->ncp));
+        SOSLAM_CHECK(h->cAinv.alloc((size_t)h->ncp * h->ncp));
+        SOSLAM_CHECK(h->cebuf.alloc(2 * 3600));
+        SOSLAM_CHECK(h->crc.alloc(h->ncp));
+        SOSLAM_CHECK(h->crc.zero(s));
+    }
     SOSLAM_CHECK(h->chi_part.alloc(std::max<uint32_t>(h->n_chi_part, div_up(n_edge, 256))));
     SOSLAM_CHECK(h->chi_part_lin.alloc(h->n_chi_part));
     SOSLAM_CHECK(h->scale_part.alloc(h->n_scale_part));
@@ -200,6 +308,9 @@ int linearize(soslam_pg* h, double* dbg_e, double* dbg_ji, double* dbg_jj)
                         h->chi_part_lin.p, dbg_e, dbg_ji, dbg_jj);
     launch_pg_gather(s, h->n_blocks, h->g_ptr.p, h->g_ent.p, h->blk_row.p, h->blk_col.p, h->econ.p, h->H.p, h->b.p);
     launch_pg_reduce(s, h->chi_part_lin.p, h->n_chi_part, h->H.p, h->diag_block.p, h->n_free, h->scal.p);
+    if (h->two_level)
+        launch_pg_coarse_setup(s, h->n_free, h->n_agg, h->free_vertex.p, h->row_agg.p, h->agg_ref.p, h->agg_ptr.p, h->est[h->cur].p, h->n_cb,
+                               h->cb_ptr.p, h->cb_ent.p, h->cb_I.p, h->cb_J.p, h->blk_row.p, h->blk_col.p, h->H.p, h->ncp, h->cP.p, h->cG.p, h->cAc0.p);
     SOSLAM_HIP_CHECK(hipGetLastError());
     return SOSLAM_OK;
 }
@@ -251,8 +362,13 @@ int run(soslam_pg* h, soslam_pg_summary* out)
             double rel = 0.0;
             int lin_it = 0;
             SOSLAM_HIP_CHECK(hipEventRecord(h->ev[0], s));
-            if (h->n_free) lin_it = pcg_multi_solve(s, bsr_view(h), lambda, h->b.p, h->x.p, h->resid.p, h->work.p, o.pcg_tolerance,
-                                                     o.pcg_max_iterations, 32, &rel);
+            if (h->n_free && h->two_level) {
+                const TwoLevelView tl{h->n_agg, h->ncp, h->agg_ptr.p, h->cP.p, h->cAinv.p, h->crc.p};
+                lin_it = pcg2_solve(s, bsr_view(h), lambda, h->b.p, h->x.p, h->resid.p, h->work.p, tl, h->cAc0.p, h->cG.p, h->cebuf.p, o.pcg_tolerance,
+                                    o.pcg_max_iterations, 32, &rel);
+            } else if (h->n_free) {
+                lin_it = pcg_multi_solve(s, bsr_view(h), lambda, h->b.p, h->x.p, h->resid.p, h->work.p, o.pcg_tolerance, o.pcg_max_iterations, 32, &rel);
+            }
             SOSLAM_HIP_CHECK(hipEventRecord(h->ev[1], s));
             const bool ok = lin_it >= 0;
             lin_total += std::max(lin_it, 0);
@@ -313,6 +429,7 @@ void soslam_pg_options_default(soslam_pg_options* o)
     o->pcg_tolerance = 1e-10;
     o->pcg_max_iterations = 4000;
     o->verbose = 0;
+    o->preconditioner = SOSLAM_PG_PRECOND_AUTO;
     o->device = -1;
     o->stream = nullptr;
 }

@@ -12,7 +12,7 @@ class PgOptions(C.Structure):
     _fields_ = [
         ("max_iterations", C.c_int32), ("max_trials", C.c_int32), ("huber_delta", C.c_double), ("tau", C.c_double),
         ("pcg_tolerance", C.c_double), ("pcg_max_iterations", C.c_int32), ("verbose", C.c_int32), ("device", C.c_int32),
-        ("reserved", C.c_int32), ("stream", C.c_void_p),
+        ("preconditioner", C.c_int32), ("stream", C.c_void_p),
     ]
 
 
