@@ -563,7 +563,9 @@ int pcg2_solve(hipStream_t s, const BsrView& A, double shift, const double* b, d
     double host_state[ST_COUNT] = {0, 0, 0, 0};
     double rr = 0.0;
     while (launched < max_iter) {
-        const int todo = std::min(chunk, max_iter - launched);
+        // the first chunk is the caller's estimate of the whole solve (the iterations its last solve took); what is left
+        // after it goes in short chunks: an unneeded launch costs 2 - 3 us, three per iteration
+        const int todo = std::min(launched == 0 ? std::max(chunk, 1) : 8, max_iter - launched);
         for (int k = 0; k < todo; k++) {
             if (launched + k == 0) hipLaunchKernelGGL(pcg2_matvec_kernel<true>, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, tl, parity, tol);
             else hipLaunchKernelGGL(pcg2_matvec_kernel<false>, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, tl, parity, tol);

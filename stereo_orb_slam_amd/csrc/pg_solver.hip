@@ -36,6 +36,7 @@ struct soslam_pg {
     DevBuf<PgEdgeBlocks> eb;
     // two-level preconditioner (pcg2_solve): aggregates of neighbouring free vertices, six rigid-body modes each
     bool two_level = false;
+    int last_lin_it = 0;                // PCG iterations of the last solve: the next solve enqueues that many before it looks
     uint32_t n_agg = 0, ncp = 0, n_cb = 0;
     DevBuf<uint32_t> agg_ptr, row_agg, agg_ref, free_vertex, cb_ptr, cb_ent, cb_I, cb_J;
     DevBuf<double> cP, cG, cAc0, cAinv, cebuf, crc;
@@ -84,9 +85,9 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     // kAggMax vertices each (one workgroup of pcg2_solve per aggregate), compact in the graph whatever the vertex numbering
     // (a lawn-mower path, a chain with loop closures).  The free indices are then renumbered aggregate by aggregate, so that
     // an aggregate is a contiguous range of block rows of H.
-    constexpr uint32_t kAggMax = 40;
+    constexpr uint32_t kAggMax = 42;   // block rows of one pcg2 workgroup
     const int pre = h->opt.preconditioner;
-    h->two_level = nf > 0 && (pre == SOSLAM_PG_PRECOND_TWO_LEVEL || (pre == SOSLAM_PG_PRECOND_AUTO && nf >= 256)) && (nf + kAggMax - 1) / kAggMax * 6 <= 1200;
+    h->two_level = nf > 0 && (pre == SOSLAM_PG_PRECOND_TWO_LEVEL || (pre == SOSLAM_PG_PRECOND_AUTO && nf >= 64)) && (nf + kAggMax - 1) / kAggMax * 6 <= 1200;
     std::vector<uint32_t> agg_ptr, row_agg, agg_ref, free_vertex(nf);
     if (h->two_level) {
         std::vector<std::vector<uint32_t>> adj(n_vertex);
@@ -94,7 +95,7 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
             if (h->h_free[ef[k]] >= 0 && h->h_free[et[k]] >= 0) { adj[ef[k]].push_back(et[k]); adj[et[k]].push_back(ef[k]); }
         // aggregate sizes: as even as the cap allows (a count of ceil(nf / kAggMax) aggregates, sizes within one of each other
         // would need a partitioner; breadth-first growth to the target size, leftovers joined to a neighbouring aggregate or kept)
-        const uint32_t target = kAggMax;
+        const uint32_t target = 34;        // growth stops here; what is left between grown aggregates is merged into them up to kAggMax
         std::vector<int32_t> agg_of(n_vertex, -1);
         std::vector<std::vector<uint32_t>> members;
         std::vector<uint32_t> queue;
@@ -115,19 +116,29 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
             for (size_t qi = members.back().size(); qi < queue.size(); qi++) agg_of[queue[qi]] = -1;
             for (uint32_t v : members.back()) agg_of[v] = id;
         }
-        // small leftovers (enclosed by full aggregates) join a neighbouring aggregate that still has room
-        for (size_t a = 0; a < members.size(); a++) {
-            if (members[a].empty() || members[a].size() > kAggMax / 4) continue;
-            int32_t best = -1;
-            for (uint32_t v : members[a])
-                for (uint32_t u : adj[v]) {
-                    const int32_t b = agg_of[u];
-                    if (b >= 0 && b != (int32_t)a && members[(size_t)b].size() + members[a].size() <= kAggMax &&
-                        (best < 0 || members[(size_t)b].size() < members[(size_t)best].size())) best = b;
+        // leftovers (pieces enclosed by grown aggregates) and small aggregates join the smallest neighbouring aggregate that has
+        // room, smallest pieces first, until nothing fits any more
+        for (bool merged = true; merged;) {
+            merged = false;
+            std::vector<size_t> order;
+            for (size_t a = 0; a < members.size(); a++)
+                if (!members[a].empty() && members[a].size() < target) order.push_back(a);
+            std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return members[x].size() != members[y].size() ? members[x].size() < members[y].size() : x < y; });
+            for (size_t a : order) {
+                if (members[a].empty()) continue;
+                int32_t best = -1;
+                for (uint32_t v : members[a])
+                    for (uint32_t u : adj[v]) {
+                        const int32_t b = agg_of[u];
+                        if (b >= 0 && b != (int32_t)a && !members[(size_t)b].empty() && members[(size_t)b].size() + members[a].size() <= kAggMax &&
+                            (best < 0 || members[(size_t)b].size() < members[(size_t)best].size() ||
+                             (members[(size_t)b].size() == members[(size_t)best].size() && b < best))) best = b;
+                    }
+                if (best >= 0) {
+                    for (uint32_t v : members[a]) { agg_of[v] = best; members[(size_t)best].push_back(v); }
+                    members[a].clear();
+                    merged = true;
                 }
-            if (best >= 0) {
-                for (uint32_t v : members[a]) { agg_of[v] = best; members[(size_t)best].push_back(v); }
-                members[a].clear();
             }
         }
         uint32_t next = 0;
@@ -140,6 +151,7 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
             agg_ptr.push_back(next);
         }
         h->n_agg = (uint32_t)agg_ptr.size() - 1;
+        h->last_lin_it = 0;
         h->ncp = (h->n_agg * 6 + 59) / 60 * 60;
     } else {
         h->n_agg = 0; h->ncp = 0;
@@ -365,7 +377,8 @@ int run(soslam_pg* h, soslam_pg_summary* out)
             if (h->n_free && h->two_level) {
                 const TwoLevelView tl{h->n_agg, h->ncp, h->agg_ptr.p, h->cP.p, h->cAinv.p, h->crc.p};
                 lin_it = pcg2_solve(s, bsr_view(h), lambda, h->b.p, h->x.p, h->resid.p, h->work.p, tl, h->cAc0.p, h->cG.p, h->cebuf.p, o.pcg_tolerance,
-                                    o.pcg_max_iterations, 32, &rel);
+                                    o.pcg_max_iterations, h->last_lin_it > 0 ? h->last_lin_it + 2 : 48, &rel);
+                if (lin_it > 0) h->last_lin_it = lin_it;
             } else if (h->n_free) {
                 lin_it = pcg_multi_solve(s, bsr_view(h), lambda, h->b.p, h->x.p, h->resid.p, h->work.p, o.pcg_tolerance, o.pcg_max_iterations, 32, &rel);
             }
@@ -579,7 +592,18 @@ int soslam_pg_debug_linearize(soslam_pg* h, double* edge_e, double* edge_ji, dou
     if (edge_e) SOSLAM_HIP_CHECK(hipMemcpy(edge_e, de.p, sizeof(double) * 6 * h->n_edge, hipMemcpyDeviceToHost));
     if (edge_ji) SOSLAM_HIP_CHECK(hipMemcpy(edge_ji, dji.p, sizeof(double) * 36 * h->n_edge, hipMemcpyDeviceToHost));
     if (edge_jj) SOSLAM_HIP_CHECK(hipMemcpy(edge_jj, djj.p, sizeof(double) * 36 * h->n_edge, hipMemcpyDeviceToHost));
-    if (b) SOSLAM_HIP_CHECK(hipMemcpy(b, h->b.p, sizeof(double) * 6 * h->n_free, hipMemcpyDeviceToHost));
+    // the caller's order of the free vertices (vertex order); internally they are numbered aggregate by aggregate (build_graph)
+    std::vector<uint32_t> nat(h->n_free);
+    {
+        uint32_t k = 0;
+        for (uint32_t v = 0; v < h->n_vertex; v++)
+            if (h->h_free[v] >= 0) nat[(size_t)h->h_free[v]] = k++;
+    }
+    if (b) {
+        std::vector<double> tmp((size_t)h->n_free * 6);
+        SOSLAM_HIP_CHECK(hipMemcpy(tmp.data(), h->b.p, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+        for (uint32_t f = 0; f < h->n_free; f++) std::memcpy(b + 6 * (size_t)nat[f], &tmp[6 * (size_t)f], 6 * sizeof(double));
+    }
     if (h_dense) {
         const size_t n6 = (size_t)h->n_free * 6;
         std::vector<double> blk((size_t)h->n_blocks * 36);
@@ -588,7 +612,7 @@ int soslam_pg_debug_linearize(soslam_pg* h, double* edge_e, double* edge_ji, dou
         for (uint32_t k = 0; k < h->n_blocks; k++)
             for (int a = 0; a < 6; a++)
                 for (int c = 0; c < 6; c++) {
-                    const size_t i = 6 * (size_t)h->h_blk_row[k] + a, j = 6 * (size_t)h->h_blk_col[k] + c;
+                    const size_t i = 6 * (size_t)nat[h->h_blk_row[k]] + a, j = 6 * (size_t)nat[h->h_blk_col[k]] + c;
                     h_dense[i * n6 + j] = blk[36 * (size_t)k + a * 6 + c];
                     h_dense[j * n6 + i] = blk[36 * (size_t)k + a * 6 + c];
                 }

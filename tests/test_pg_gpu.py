@@ -117,6 +117,43 @@ def test_config5_full_size_matches_oracle(gpu, oracle_lib):
     _same_rotation(est[:, 3:], oest[:, 3:], 1e-4)
 
 
+def test_two_level_preconditioner_cuts_the_iterations_not_the_answer(gpu):
+    """The reference solves the Levenberg system directly (LinearSolverEigen, /root/reference/src/pose_graph_optimizer.cpp:14-18);
+    here PCG does, and its preconditioner must not show in the result: block-Jacobi alone and block-Jacobi plus the
+    rigid-body coarse space (the default from 64 free vertices on) give the same ten iterations - chi2, lambda, trials, poses -
+    while the coarse space takes a fraction of the PCG iterations (task 4: <= 100 per Levenberg step).  Also a
+    chain with few loop closures, the shape the reference's own graphs have (odometry + loop edges)."""
+    pg, synth, L = gpu
+    g = synth.generate_pg(5)
+    res = {}
+    for pre in (1, 2):
+        with pg.PoseGraph(pg.default_options(max_iterations=10, preconditioner=pre)) as h:
+            h.load(g)
+            s = h.optimize()
+            res[pre] = (s, h.estimates(), h.iteration_log())
+    (s1, e1, l1), (s2, e2, l2) = res[1], res[2]
+    assert s1.iterations == s2.iterations == 10
+    for a, b in zip(l1, l2):
+        assert a.chi2 == pytest.approx(b.chi2, rel=1e-8) and a.trials == b.trials and a.lam == pytest.approx(b.lam, rel=1e-6)
+    np.testing.assert_allclose(e1[:, :3], e2[:, :3], atol=1e-6)
+    _same_rotation(e1[:, 3:], e2[:, 3:], 1e-6)
+    per_solve = [it.linear_iterations / max(1, it.trials) for it in l2]
+    assert max(per_solve) <= 100, per_solve
+    assert s2.linear_iterations * 5 < s1.linear_iterations, (s1.linear_iterations, s2.linear_iterations)
+    # a chain with a handful of closures: 600 vertices in one long row (no lattice), 12 loop edges
+    c = synth.generate_pg(5, n_node=600, row_len=600, n_loop_max=12, min_gap=50, radius=80.0)
+    out = {}
+    for pre in (1, 2):
+        with pg.PoseGraph(pg.default_options(max_iterations=10, preconditioner=pre)) as h:
+            h.load(c)
+            s = h.optimize()
+            out[pre] = (s, h.estimates())
+    assert out[1][0].final_chi2 == pytest.approx(out[2][0].final_chi2, rel=1e-7)
+    np.testing.assert_allclose(out[1][1][:, :3], out[2][1][:, :3], atol=1e-5)
+    # (on a one-dimensional chain the piecewise-rigid coarse space gains less than on the lattice: measured 5 080 -> 2 789)
+    assert out[2][0].linear_iterations * 3 < out[1][0].linear_iterations * 2, (out[1][0].linear_iterations, out[2][0].linear_iterations)
+
+
 def test_linearisation_is_bitwise_reproducible(gpu):
     """H and b are summed from per-edge records through fixed-order lists (pg_gather), not by floating-point atomics: two
     linearisations of the same estimates agree bit for bit, and so do two whole solves."""
