@@ -86,3 +86,15 @@ def test_pose_matrix_round_trip(soslam):
     assert np.isfinite(T).all()
     np.testing.assert_allclose(T.reshape(4, 4)[:3, :3], np.eye(3), atol=0)
     np.testing.assert_allclose(T.reshape(4, 4)[:3, 3], [-1, -2, -3], atol=1e-6)
+
+
+def test_no_kernel_is_over_its_register_budget():
+    """The build's own check (csrc/Makefile runs it after the link): no gfx950 kernel of the library spills vector registers or
+    uses scratch memory, except the two that are listed and tested that way.  VERDICT round 2, task 5: the windowed Schur kernel
+    sits two registers under its budget, and the variant that went over it was only noticed on the device."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_kernel_resources.py"),
+                        os.path.join(root, "stereo_orb_slam_amd", "libsoslam_ba.so")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
