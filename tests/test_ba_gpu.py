@@ -936,3 +936,29 @@ def test_two_block_dense_solve_matches_the_blocked_cholesky(gpu):
         np.testing.assert_allclose(new["cost"], old["cost"], rtol=1e-10)
         np.testing.assert_allclose(new["cams"], old["cams"], rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(new["pts"], old["pts"], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["reject", "bounds"])
+@pytest.mark.parametrize("solver", [1, 2])
+def test_trust_region_trajectory_matches_the_independent_restatement(gpu, golden_dir, tag, solver):
+    """The device path's controller against the numpy / autograd restatement of the whole loop (oracle/gen_controller_golden.py;
+    tests/test_oracle_golden.py holds the oracle to the same records): rejected steps and their radius factors, the Armijo
+    search with cubic interpolation on the problem with active bounds."""
+    from test_oracle_golden import _check_ba_trajectory
+    ba, synth, L = gpu
+    g = np.load(os.path.join(golden_dir, "ba_lm_trajectory.npz"), allow_pickle=False)
+    n = len(g[tag + "_radius"])
+    fixed = np.zeros(len(g[tag + "_cams0"]), np.uint8)
+    fixed[0] = 1
+    kw = dict(linear_solver=solver, max_iterations=n, check_termination=0, lower_bound=float(g[tag + "_lo"]), upper_bound=float(g[tag + "_hi"]),
+              pcg_tolerance=1e-13)
+    if tag + "_radius0" in g.files:
+        kw["initial_radius"] = float(g[tag + "_radius0"])
+    with ba.BundleAdjustment(ba.default_options(**kw)) as h:
+        h.set_projection(g["proj_l"], g["proj_r"])
+        h.set_problem(len(fixed), len(g[tag + "_pts0"]), g["obs_cam"], g["obs_pt"], g["obs_uv"], fixed)
+        h.set_state(g[tag + "_cams0"], g[tag + "_pts0"])
+        summ = h.iterate(n)
+        log = h.iteration_log()
+        cams, _ = h.get_state()
+    _check_ba_trajectory(g, tag, log, summ.line_search_steps, summ.final_cost, cams)

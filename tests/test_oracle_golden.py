@@ -124,3 +124,71 @@ def test_invalid_steps_halve_the_radius(oracle_lib):
     assert [e.radius for e in log[1:]] == [1e4, 5e3, 2.5e3, 1.25e3]
     _, _, s, _ = oracle_lib.solve(*args, oracle_lib.default_options(max_iterations=20, min_lm_diagonal=0.0))
     assert s.iterations == 5 and s.termination == 5   # ORACLE_TERM_INVALID_STEPS
+
+
+# ---- the controllers against an independent restatement of the whole loop (oracle/gen_controller_golden.py) -----------------------
+
+def _check_ba_trajectory(g, tag, log, line_search_steps, final_cost, cams):
+    """log: the iteration records of the oracle or of the device path (entry 0 = the initial point)."""
+    n = len(g[tag + "_radius"])
+    its = log[1:n + 1]
+    assert [int(e.accepted) for e in its] == g[tag + "_accepted"].tolist()
+    assert [int(e.valid) for e in its] == g[tag + "_valid"].tolist()
+    np.testing.assert_allclose([e.radius for e in its], g[tag + "_radius"], rtol=1e-6)
+    np.testing.assert_allclose([e.model_cost_change for e in its], g[tag + "_model"], rtol=1e-6)
+    np.testing.assert_allclose([e.candidate_cost for e in its], g[tag + "_cand"], rtol=1e-7)
+    np.testing.assert_allclose([e.relative_decrease for e in its], g[tag + "_rho"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose([e.step_norm for e in its], g[tag + "_step_norm"], rtol=1e-6)
+    assert line_search_steps == int(g[tag + "_ls_iters"].sum())
+    assert final_cost == pytest.approx(float(g[tag + "_final_cost"]), rel=1e-8)
+    np.testing.assert_allclose(cams, g[tag + "_cams"], atol=1e-7)
+
+
+def _ba_options(oracle_lib, g, tag):
+    kw = dict(max_iterations=len(g[tag + "_radius"]), check_termination=0, lower_bound=float(g[tag + "_lo"]), upper_bound=float(g[tag + "_hi"]))
+    if tag + "_radius0" in g.files:
+        kw["initial_radius"] = float(g[tag + "_radius0"])
+    return kw
+
+
+@pytest.mark.parametrize("tag", ["reject", "bounds"])
+def test_trust_region_trajectory_matches_the_independent_restatement(oracle_lib, golden_dir, tag):
+    """Radius sequence through accepted and rejected steps ("reject": 14 iterations, five rejections, factors 2, 4, growth through
+    1 / max(1/3, 1 - (2 rho - 1)^3)) and the bounded problem's Armijo search with cubic interpolation ("bounds": three
+    iterations whose full projected step fails the sufficient-decrease test and is contracted to 0.21..) - every iteration's
+    radius, model cost change, candidate cost, step quality and step norm against the numpy / autograd restatement."""
+    g = _load(golden_dir, "ba_lm_trajectory.npz")
+    fixed = np.zeros(len(g[tag + "_cams0"]), np.uint8)
+    fixed[0] = 1
+    o = oracle_lib.default_options(**_ba_options(oracle_lib, g, tag))
+    cams, pts, summ, log = oracle_lib.solve(g["obs_cam"], g["obs_pt"], g["obs_uv"], g[tag + "_cams0"], g[tag + "_pts0"], g["proj_l"],
+                                            g["proj_r"], fixed, o)
+    _check_ba_trajectory(g, tag, log, summ.line_search_steps, summ.final_cost, cams)
+    if tag == "reject":
+        assert (g["reject_accepted"] == 0).sum() >= 4
+    else:
+        assert (g["bounds_alpha"] < 1.0).sum() >= 3 and g["bounds_ls_iters"].sum() >= 3
+
+
+def test_levenberg_schedule_matches_the_independent_restatement(oracle_lib, golden_dir):
+    """g2o's lambda / nu schedule on a 12-vertex graph from a poor start (one rejected trial on the way): chi2, lambda and the
+    number of trials of every iteration against the numpy / autograd restatement."""
+    import ctypes as C
+    g = _load(golden_dir, "pg_lm_trajectory.npz")
+    L = oracle_lib.lib()
+    o = oracle_lib.PgOptions()
+    L.oracle_pg_options_default(C.byref(o))
+    n_it = len(g["chi2"])
+    o.max_iterations = n_it
+    est = g["est0"].copy()
+    fixed = np.zeros(len(est), np.uint8)
+    fixed[0] = 1
+    s = oracle_lib.PgSummary()
+    log = (oracle_lib.PgIteration * n_it)()
+    rc = L.oracle_pg_solve(len(est), len(g["e_from"]), est, fixed, np.ascontiguousarray(g["e_from"]), np.ascontiguousarray(g["e_to"]),
+                           np.ascontiguousarray(g["meas"]), np.ascontiguousarray(g["info"]), C.byref(o), C.byref(s), C.cast(log, C.c_void_p))
+    assert rc == 0 and s.iterations == n_it
+    assert [e.trials for e in log] == g["trials"].tolist() and max(g["trials"]) >= 2
+    np.testing.assert_allclose([e.chi2 for e in log], g["chi2"], rtol=1e-6)
+    np.testing.assert_allclose([e.lam for e in log], g["lam"], rtol=1e-5)
+    np.testing.assert_allclose(est[:, :3], g["est"][:, :3], atol=1e-6)

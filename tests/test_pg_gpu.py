@@ -249,3 +249,22 @@ def test_appended_graph_equals_the_whole_graph(gpu):
         h.set_graph(np.concatenate([e1, g.est[v1:]]), g.fixed, g.e_from[order], g.e_to[order], g.meas[order], g.info)
         h.optimize()
         np.testing.assert_array_equal(grown, h.estimates())
+
+
+def test_levenberg_schedule_matches_the_independent_restatement(gpu, golden_dir):
+    """The device path's Levenberg controller against the numpy / autograd restatement of g2o's loop
+    (oracle/gen_controller_golden.py): chi2, lambda and the trials of every iteration, one rejected trial on the way."""
+    pg, synth, L = gpu
+    g = np.load(os.path.join(golden_dir, "pg_lm_trajectory.npz"), allow_pickle=False)
+    n_it = len(g["chi2"])
+    fixed = np.zeros(len(g["est0"]), np.uint8)
+    fixed[0] = 1
+    with pg.PoseGraph(pg.default_options(max_iterations=n_it, pcg_tolerance=1e-13)) as h:
+        h.set_graph(g["est0"], fixed, g["e_from"], g["e_to"], g["meas"], g["info"])
+        s = h.optimize()
+        est, log = h.estimates(), h.iteration_log()
+    assert s.iterations == n_it
+    assert [e.trials for e in log] == g["trials"].tolist()
+    np.testing.assert_allclose([e.chi2 for e in log], g["chi2"], rtol=1e-6)
+    np.testing.assert_allclose([e.lam for e in log], g["lam"], rtol=1e-5)
+    np.testing.assert_allclose(est[:, :3], g["est"][:, :3], atol=1e-6)
