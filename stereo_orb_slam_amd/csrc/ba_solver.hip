@@ -809,7 +809,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->lin_resid.zero(s));
     if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
         const size_t n6 = (size_t)nf * 6;
-        SOSLAM_CHECK(h->dense.alloc(n6 * n6 + (size_t)div_up(n6, 32) * 32 * 32 + 1024));
+        SOSLAM_CHECK(h->dense.alloc(std::max(n6 * n6 + (size_t)div_up(n6, 32) * 32 * 32 + 1024, dense_inverse_fits(nf) ? dense_inverse_count(nf) : (size_t)0)));
     } else {
         h->dense.release();
     }
@@ -1056,6 +1056,8 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                     launch_dense2_solve(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->rhs(), h->dc_free.p, h->scalp());
                 } else if (dense_small_fits(h->n_free)) {
                     launch_dense_small_solve(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->rhs(), h->dc_free.p, h->scalp());
+                } else if (dense_inverse_fits(h->n_free) && std::getenv("SOSLAM_DENSE_CHOLESKY") == nullptr) {
+                    launch_dense_inverse_solve(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
                 } else {
                     launch_bsr_to_dense(s, bsr_view(h), h->n_blocks, h->blk_row.p, h->blk_col.p, h->dense.p);
                     launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());

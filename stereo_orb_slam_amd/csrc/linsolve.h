@@ -40,6 +40,13 @@ void launch_bsr_to_dense(hipStream_t s, const BsrView& A, uint32_t n_blocks, con
                          const uint32_t* blk_col, double* dense);
 void launch_dense_cholesky_solve(hipStream_t s, uint32_t n, double* dense, const double* b, double* x, double* scal);
 
+// up to 1 260 unknowns: S padded to tiles of 60, inverted explicitly (block Gauss-Jordan on the matrix cores), two dense products
+// and one refinement against the block-sparse S; work: dense_inverse_count(n_rows) f64
+bool dense_inverse_fits(uint32_t n_rows);
+size_t dense_inverse_count(uint32_t n_rows);
+void launch_dense_inverse_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
+                                double* work, const double* b, double* x, double* scal);
+
 size_t pcg_work_count(uint32_t n_rows);
 
 // Small systems (<= kDenseSmallRowsMax block rows: the reference's sliding windows): S expanded, factored and solved by

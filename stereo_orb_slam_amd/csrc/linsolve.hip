@@ -506,6 +506,67 @@ __global__ __launch_bounds__(kSmallThreads) void dense_small_solve_kernel(const 
     if (tid < n) x[tid] = v[tid];
 }
 
+
+// ---- dense systems up to 1 260 unknowns: explicit inverse by block Gauss-Jordan (crsolve.hip) + one round of refinement -------
+// The blocked right-looking Cholesky below pays 3 launches per 32 columns with a single-workgroup diagonal step (34 us) and a
+// single-workgroup triangular solve behind it (290 us at 594 unknowns: BASELINE.json configs[1] took 1.25 ms per solve).  With
+// the matrix padded to tiles of 60 and inverted explicitly on the f64 matrix cores (3 launches per 60 columns, every one a grid
+// of products) the solve is two dense products and - as the one-workgroup solvers do - one refinement against the block-sparse
+// S itself, which takes the explicit inverse's rounding out of the result.
+__global__ __launch_bounds__(256) void dense60_fill_kernel(const uint32_t n, const uint32_t ncp, double* __restrict__ dense)
+{
+    // zero, with the identity on the padding
+    const uint32_t row = blockIdx.x;
+    for (uint32_t col = threadIdx.x; col < ncp; col += 256) dense[(size_t)row * ncp + col] = (row >= n && row == col) ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(64) void dense60_scatter_kernel(const double* __restrict__ blocks, const uint32_t* __restrict__ blk_row,
+                                                             const uint32_t* __restrict__ blk_col, const uint32_t ncp, double* __restrict__ dense)
+{
+    const uint32_t blk = blockIdx.x;
+    const int t = threadIdx.x;
+    if (t >= 36) return;
+    const uint32_t i = 6 * blk_row[blk] + t / 6, j = 6 * blk_col[blk] + t % 6;
+    const double v = blocks[36 * (size_t)blk + t];
+    dense[(size_t)i * ncp + j] = v;
+    dense[(size_t)j * ncp + i] = v;
+}
+
+// out = base + Ainv v (one wave per row, lane-strided sum in a fixed order); MODE 1: v = b - S x first (written to r)
+__global__ __launch_bounds__(256) void dense60_apply_kernel(const double* __restrict__ Ainv, const uint32_t ncp, const uint32_t n,
+                                                            const double* __restrict__ v, const double* __restrict__ base, double* __restrict__ out)
+{
+    const uint32_t row = blockIdx.x * 4 + threadIdx.x / 64;
+    const int lane = threadIdx.x % 64;
+    if (row >= n) return;
+    double sum = 0.0;
+    const double* a = Ainv + (size_t)row * ncp;
+    for (uint32_t j = lane; j < n; j += 64) sum += a[j] * v[j];
+    sum = wave_sum(sum);
+    if (lane == 0) out[row] = (base ? base[row] : 0.0) + sum;
+}
+
+__global__ __launch_bounds__(256) void bsr_residual_kernel(const BsrView A, const double* __restrict__ b, const double* __restrict__ x,
+                                                           double* __restrict__ r)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n_rows * 6) return;
+    const uint32_t f = i / 6, a = i % 6;
+    double s = b[i];
+    for (uint32_t e = A.row_ptr[f]; e < A.row_ptr[f + 1]; e++) {
+        const double* B = A.blocks + 36 * (size_t)A.ent_blk[e];
+        const double* xv = x + 6 * (size_t)A.ent_col[e];
+        if (A.ent_trans[e]) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) s -= B[c * 6 + a] * xv[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) s -= B[a * 6 + c] * xv[c];
+        }
+    }
+    r[i] = s;
+}
+
 }  // namespace
 
 bool dense_small_fits(uint32_t n_rows) { return n_rows >= 1 && n_rows <= (uint32_t)kDenseSmallRowsMax; }
@@ -544,6 +605,32 @@ void launch_dense_cholesky_solve(hipStream_t s, uint32_t n, double* dense, const
         }
     }
     hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(1024), 0, s, dense, n, dinv, b, x);
+}
+
+bool dense_inverse_fits(uint32_t n_rows) { return n_rows >= 1 && n_rows * 6 <= 1260; }
+
+size_t dense_inverse_count(uint32_t n_rows)
+{
+    const size_t ncp = ((size_t)n_rows * 6 + 59) / 60 * 60;
+    return ncp * ncp + 2 * 3600 + 3 * ncp;
+}
+
+void launch_dense_inverse_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
+                                double* work, const double* b, double* x, double* scal)
+{
+    const uint32_t n = A.n_rows * 6;
+    if (!n) return;
+    const uint32_t ncp = (n + 59) / 60 * 60;
+    double* dense = work;
+    double* ebuf = dense + (size_t)ncp * ncp;
+    double* x0 = ebuf + 2 * 3600;
+    double* r = x0 + ncp;
+    hipLaunchKernelGGL(dense60_fill_kernel, dim3(ncp), dim3(256), 0, s, n, ncp, dense);
+    hipLaunchKernelGGL(dense60_scatter_kernel, dim3(n_blocks), dim3(64), 0, s, A.blocks, blk_row, blk_col, ncp, dense);
+    launch_dense_spd_inverse60(s, dense, (int)(ncp / 60), ebuf, scal + SC_LIN_STATUS);
+    hipLaunchKernelGGL(dense60_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dense, ncp, n, b, nullptr, x0);
+    hipLaunchKernelGGL(bsr_residual_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, b, x0, r);
+    hipLaunchKernelGGL(dense60_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, s, dense, ncp, n, r, x0, x);
 }
 
 }  // namespace soslam
