@@ -13,7 +13,14 @@ namespace soslam {
 constexpr int kTileObs = 1024;       // observations per linearize/cost workgroup (one camera per tile)
 constexpr int kTileThreads = 256;    // lanes per tile: up to 4 observations each
 constexpr int kTileVals = 28;        // 21 (J_c^T J_c upper) + 6 (J_c^T r) + 1 (rho)
-constexpr int kArRow = 10;            // f64 per observation in the compact row array [G (xx xy xz yy yz zz) | h (3) | 0], 80 B
+constexpr int kArRow = 10;            // f64 per observation in the compact row: [G (xx xy xz yy yz zz)] 48 B + [h (3) | 0] 32 B
+constexpr int kArG = 6, kArH = 4;     // ... held as TWO arrays: every pass after the linearisation gathers rows through the point-major
+                                      // index, and most of them (back-substitution, the Schur products) want G only - with one
+                                      // 80-B row per observation they fetched 1.7x the bytes they used (PMC, round 2)
+struct CompactRows {
+    double* g;                        // [n_obs][6]
+    double* h;                        // [n_obs][4]
+};
 constexpr int kBatchObs = 128;       // observations staged per Schur batch (also the most one windowed point may have)
 // points per Schur batch: the batch's point columns (3 each) are the k dimension of the window GEMM, and two
 // [3 PB][6 KMAX + 1] f64 images must fit LDS next to the staged rows
@@ -105,7 +112,7 @@ void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, doub
 
 void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
                       const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
-                      double* ar, double* tile_part, const double* gate = nullptr /* != NULL: run only if *gate != 0 */);
+                      CompactRows ar, double* tile_part, const double* gate = nullptr /* != NULL: run only if *gate != 0 */);
 
 // parity tests: residual (n_obs*4), J_c (n_obs*24), J_p (n_obs*12) of every observation, internal observation order
 void launch_debug_rows(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
@@ -139,7 +146,7 @@ void launch_gate_publish(hipStream_t s, double* scal, double x_cost, double min_
 void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out);
 
 void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
-                         const double* ar, const double* campre, double* C, double* gp, const double* gate = nullptr);
+                         CompactRows ar, const double* campre, double* C, double* gp, const double* gate = nullptr);
 
 void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacobi, double* sp);
 
@@ -148,7 +155,7 @@ constexpr int kS10PairsPerBatch = 120;   // (point, window slot) pairs of a batc
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
                   const uint32_t* chunk_slab, const uint32_t* chunk_cam /* [n_chunks][kmax] camera of each window slot */,
                   const uint32_t* pair_row /* kmax <= 10: [n_batches][120] row of (point pl, slot) at pl * n_local + slot, or ~0 */,
-                  const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, const double* ar, const double* campre,
+                  const uint32_t* pt_obs, const uint32_t* q_pt, const uint8_t* q_slot, CompactRows ar, const double* campre,
                   const double* pts, double* C, double* gp, const double* sp, LmDiag lm, double* Cinv,
                   double* ptfac /* [n_pt][12] scratch: L^-T and L^-1 g of the damped point blocks, position */, double* slab, double* scal,
                   const uint32_t* pt_start, const uint32_t* q_cam,

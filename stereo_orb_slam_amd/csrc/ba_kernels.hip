@@ -71,14 +71,13 @@ __global__ __launch_bounds__(64) void ba_pose_prepare_kernel(uint32_t n_cam, con
 __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
     const Tile* __restrict__ tiles, const float4* __restrict__ uv, const uint32_t* __restrict__ obs_pt,
     const double* __restrict__ campre, const double* __restrict__ pts, const int32_t* __restrict__ cam_free,
-    const Proj P, const double delta, double* __restrict__ ar_out, double* __restrict__ tile_part,
+    const Proj P, const double delta, const CompactRows ar_out, double* __restrict__ tile_part,
     const double* __restrict__ gate)
 {
     if (gate && *gate == 0.0) return;   // speculative launch (see ba_step_sums_kernel): the step was not accepted
     // Row-per-lane stores would touch 64 different lines per instruction; instead each wave stages its 64 rows
-    // in LDS (rows padded to 18 doubles: conflict-free ds_write_b128) and writes them back out as whole
-    // 1-KiB pieces, 16 contiguous bytes per lane.
-    constexpr int kArPad = 10;   // 80-B rows: 16-byte aligned, and stride 20 dwords keeps the ds_write_b128 conflict-free enough
+    // in LDS (the G rows, then the h rows) and writes them back out as whole 1-KiB pieces, 16 contiguous bytes per lane.
+    constexpr int kArPad = kArG + kArH;   // staging doubles per row
     __shared__ double red[(kTileThreads / kWave) * kTileVals];
     __shared__ __attribute__((aligned(16))) double stage[(kTileThreads / kWave) * kWave * kArPad];
     const Tile t = tiles[blockIdx.x];
@@ -172,20 +171,28 @@ __global__ __launch_bounds__(kTileThreads) void ba_linearize_kernel(
         }
         if (n_rows > 0) {
             const size_t row0 = (size_t)t.start + wave_first;
-            // [G | h | 0] with G = A^T A, h = A^T r: 64 rows x 10 doubles
+            // G = A^T A (64 rows x 6 doubles, 3 KiB) and [h | 0], h = A^T r (64 rows x 4 doubles, 2 KiB): two contiguous blocks
             if (act) {
-                double2* w2 = reinterpret_cast<double2*>(wstage + lane * kArPad);
-                w2[0] = make_double2(G[0], G[1]); w2[1] = make_double2(G[2], G[3]); w2[2] = make_double2(G[4], G[5]);
-                w2[3] = make_double2(hh[0], hh[1]); w2[4] = make_double2(hh[2], 0.0);
+                double2* wg = reinterpret_cast<double2*>(wstage + lane * kArG);
+                double2* wh = reinterpret_cast<double2*>(wstage + kWave * kArG + lane * kArH);
+                wg[0] = make_double2(G[0], G[1]); wg[1] = make_double2(G[2], G[3]); wg[2] = make_double2(G[4], G[5]);
+                wh[0] = make_double2(hh[0], hh[1]); wh[1] = make_double2(hh[2], 0.0);
             }
             __builtin_amdgcn_wave_barrier();
             {
-                double2* g = reinterpret_cast<double2*>(ar_out + kArRow * row0);
+                double2* g = reinterpret_cast<double2*>(ar_out.g + kArG * row0);
+                double2* hrow = reinterpret_cast<double2*>(ar_out.h + kArH * row0);
+                const double2* sg = reinterpret_cast<const double2*>(wstage);
+                const double2* sh = reinterpret_cast<const double2*>(wstage + kWave * kArG);
 #pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    const int c = i * kWave + lane;           // 16-byte piece of the wave's 5-KiB block
-                    const int row = c / 5;
-                    if (row < n_rows) g[c] = reinterpret_cast<const double2*>(wstage)[c];   // staged rows are contiguous (pad = row)
+                for (int i = 0; i < 3; i++) {
+                    const int c = i * kWave + lane;           // 16-byte piece of the wave's 3-KiB block of G rows
+                    if (c / 3 < n_rows) g[c] = sg[c];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int c = i * kWave + lane;           // 16-byte piece of the wave's 2-KiB block of h rows
+                    if (c / 2 < n_rows) hrow[c] = sh[c];
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -467,7 +474,7 @@ __device__ __forceinline__ void cam_block_from_tiles(const uint32_t cam, const u
 __global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n_pt, const uint32_t* __restrict__ pt_start,
                                                                       const uint32_t* __restrict__ pt_obs,
                                                                       const uint32_t* __restrict__ q_cam,
-                                                                      const double* __restrict__ ar,
+                                                                      const CompactRows ar,
                                                                       const double* __restrict__ campre,
                                                                       double* __restrict__ C, double* __restrict__ gp,
     const double* __restrict__ gate)
@@ -481,11 +488,15 @@ __global__ __launch_bounds__(kPointBlock) void ba_point_reduce_kernel(uint32_t n
     double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, g0 = 0, g1 = 0, g2 = 0;
     if (live) {
         for (uint32_t q = pt_start[p] + sub; q < pt_start[p + 1]; q += kBacksubLanes) {
-            const double2* row = reinterpret_cast<const double2*>(ar + kArRow * (size_t)pt_obs[q]);
+            const size_t k = pt_obs[q];
+            const double2* row = reinterpret_cast<const double2*>(ar.g + kArG * k);
+            const double2* hrow = reinterpret_cast<const double2*>(ar.h + kArH * k);
             const double* Rc = campre + kPoseStride * (size_t)q_cam[q];
             double w[10], R[10], z[9];
 #pragma unroll
-            for (int i = 0; i < 5; i++) { const double2 d = row[i]; w[2 * i] = d.x; w[2 * i + 1] = d.y; }
+            for (int i = 0; i < 3; i++) { const double2 d = row[i]; w[2 * i] = d.x; w[2 * i + 1] = d.y; }
+#pragma unroll
+            for (int i = 0; i < 2; i++) { const double2 d = hrow[i]; w[6 + 2 * i] = d.x; w[7 + 2 * i] = d.y; }
 #pragma unroll
             for (int i = 0; i < 5; i++) { const double2 d = reinterpret_cast<const double2*>(Rc)[i]; R[2 * i] = d.x; R[2 * i + 1] = d.y; }
             compact_gr(w, R, z);                       // Z = G R;  J_p^T J_p = R^T Z,  J_p^T r = R^T h
@@ -828,7 +839,7 @@ __global__ __launch_bounds__(schur_threads(KMAX), KMAX <= 10 ? 3 : 2) void ba_sc
 #pragma unroll
         for (int s = 0; s < PPT; s++) {
             // unconditional: idle lanes carry row 0 from fetch_index and read a valid (cached) piece they never store
-            const uint32_t off = pre_row[s] * (uint32_t)(kArRow * 8) + p_part(s) * 16u;
+            const uint32_t off = pre_row[s] * (uint32_t)(kArG * 8) + p_part(s) * 16u;
             const double2 v = *reinterpret_cast<const double2*>(ar_b + off);
             pre_x[s] = v.x; pre_y[s] = v.y;
         }
@@ -999,7 +1010,7 @@ static_assert(kS10PairsPerBatch == kS10PB * kS10Kmax && 2 * kS10PairsPerBatch <=
 
 __global__ __launch_bounds__(kS10Threads, 4) void ba_schur10_kernel(
     const SchurChunk* __restrict__ chunks, const SchurBatch* __restrict__ batches, const uint32_t* __restrict__ chunk_slab,
-    const uint32_t* __restrict__ chunk_cam, const uint32_t* __restrict__ pair_row, const double* __restrict__ ar,
+    const uint32_t* __restrict__ chunk_cam, const uint32_t* __restrict__ pair_row, const CompactRows ar,
     const double* __restrict__ campre, const double* __restrict__ pts, double* __restrict__ C,
     double* __restrict__ gp, const double* __restrict__ sp, const LmDiag lm, double* __restrict__ Cinv,
     double* __restrict__ ptfac, double* __restrict__ slab, double* __restrict__ scal, const uint32_t* __restrict__ pt_start,
@@ -1075,9 +1086,13 @@ __global__ __launch_bounds__(kS10Threads, 4) void ba_schur10_kernel(
                         double2 rw[kRows][5];
 #pragma unroll
                         for (int u = 0; u < kRows; u++) {
-                            const double2* row = reinterpret_cast<const double2*>(ar + kArRow * (size_t)(rk[u0 + u] != 0xFFFFFFFFu ? rk[u0 + u] : 0u));
+                            const size_t kr = rk[u0 + u] != 0xFFFFFFFFu ? rk[u0 + u] : 0u;
+                            const double2* row = reinterpret_cast<const double2*>(ar.g + kArG * kr);
+                            const double2* hrow = reinterpret_cast<const double2*>(ar.h + kArH * kr);
 #pragma unroll
-                            for (int i = 0; i < 5; i++) rw[u][i] = row[i];
+                            for (int i = 0; i < 3; i++) rw[u][i] = row[i];
+#pragma unroll
+                            for (int i = 0; i < 2; i++) rw[u][3 + i] = hrow[i];
                         }
 #pragma unroll
                         for (int u = 0; u < kRows; u++) {
@@ -1223,7 +1238,7 @@ __global__ __launch_bounds__(kS10Threads, 4) void ba_schur10_kernel(
 #pragma unroll
         for (int s = 0; s < kPiecePasses; s++) {
             const bool has = rowi[s] != 0xFFFFFFFFu;
-            const double2 v2 = reinterpret_cast<const double2*>(ar + kArRow * (size_t)(has ? rowi[s] : 0u))[pc_part[s]];
+            const double2 v2 = reinterpret_cast<const double2*>(ar.g + kArG * (size_t)(has ? rowi[s] : 0u))[pc_part[s]];
             gpiece[s] = has ? v2 : make_double2(0.0, 0.0);
         }
         if (ct < PB * 6) {
@@ -1319,7 +1334,7 @@ __global__ __launch_bounds__(64) void ba_long_prepare_kernel(const LongPoint* __
     const double g0 = gp[3 * p], g1 = gp[3 * p + 1], g2 = gp[3 * p + 2];
     const double x[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
     for (uint32_t lo = lp.lo_begin + threadIdx.x; lo < lp.lo_end; lo += 64) {
-        const double* a = ar + kArRow * (size_t)lo_row[lo];
+        const double* a = ar + kArG * (size_t)lo_row[lo];
         const double* pc = campre + kPoseStride * (size_t)lo_cam[lo];
         double G[6], R[9], v[3], w[18];
 #pragma unroll
@@ -1541,7 +1556,7 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
         for (uint32_t q = pt_start[p] + sub; q < pt_start[p + 1]; q += kBacksubLanes) {
             const size_t k = pt_obs[q];
             const size_t cam = q_cam[q];
-            const double2* row = reinterpret_cast<const double2*>(ar + kArRow * k);
+            const double2* row = reinterpret_cast<const double2*>(ar + kArG * k);
             const double* pc = campre + kPoseStride * cam;
             const double* d = dcw + 6 * cam;
             double G[6], R[10];
@@ -1611,7 +1626,7 @@ void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, doub
 
 void launch_linearize(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt,
                       const double* campre, const double* pts, const int32_t* cam_free, const Proj& P, double delta,
-                      double* ar, double* tile_part, const double* gate)
+                      CompactRows ar, double* tile_part, const double* gate)
 {
     if (!n_tiles) return;
     hipLaunchKernelGGL(ba_linearize_kernel, dim3(n_tiles), dim3(kTileThreads), 0, s, tiles, uv, obs_pt, campre, pts,
@@ -1676,7 +1691,7 @@ void launch_sum5(hipStream_t s, const double* in, uint32_t n, double* out)
 }
 
 void launch_point_reduce(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,
-                         const double* ar, const double* campre, double* C, double* gp, const double* gate)
+                         CompactRows ar, const double* campre, double* C, double* gp, const double* gate)
 {
     if (!n_pt) return;
     hipLaunchKernelGGL(ba_point_reduce_kernel, dim3(backsub_blocks(n_pt)), dim3(kPointBlock), 0, s, n_pt, pt_start, pt_obs, q_cam, ar,
@@ -1692,7 +1707,7 @@ void launch_point_scale(hipStream_t s, uint32_t n_pt, const double* C, int jacob
 
 void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* chunks, const SchurBatch* batches,
                   const uint32_t* chunk_slab, const uint32_t* chunk_cam, const uint32_t* pair_row, const uint32_t* pt_obs, const uint32_t* q_pt,
-                  const uint8_t* q_slot, const double* ar, const double* campre, const double* pts, double* C, double* gp,
+                  const uint8_t* q_slot, CompactRows ar, const double* campre, const double* pts, double* C, double* gp,
                   const double* sp, LmDiag lm, double* Cinv, double* ptfac, double* slab, double* scal, const uint32_t* pt_start,
                   const uint32_t* q_cam, int point_blocks_from_rows)
 {
@@ -1713,12 +1728,12 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
         constexpr size_t lds = SchurShape<16>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ba_schur_kernel<16>), dim3(n_chunks), dim3(schur_threads(16)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
-                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
+                           q_pt, q_slot, ar.g, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
     } else {
         constexpr size_t lds = SchurShape<32>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(schur_threads(32)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
-                           q_pt, q_slot, ar, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
+                           q_pt, q_slot, ar.g, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
     }
 }
 

@@ -156,6 +156,7 @@ struct soslam_ba {
     std::vector<StageMark> marks;
     size_t ev_used = 0;
 
+    CompactRows rows() const { return CompactRows{ar.p, ar.p + (size_t)kArG * n_obs}; }   // G rows, then the h rows (ba_kernels.h)
     double* S() const { return reduce; }
     double* rhs() const { return reduce + (size_t)n_blocks * 36; }
     double* diagB() const { return rhs() + (size_t)n_free * 6; }
@@ -888,14 +889,14 @@ int linearize(soslam_ba* h, bool in_lm_loop = false)
         if (!h->campre_current) launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);
         h->campre_current = false;
         launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p,
-                         h->proj, h->opt.huber_delta, h->ar.p, h->tile_part.p);
+                         h->proj, h->opt.huber_delta, h->rows(), h->tile_part.p);
         // the cost at this point: known on the host after an accepted step (it was the candidate's cost, summed over
         // ranks); summed from the tiles only for a state the loop has not evaluated yet
         if (!h->x_cost_known) launch_sum_strided(s, h->tile_part.p, h->n_tiles, kTileVals, 27, 0.5, h->scalp() + SC_COST_X);
     }
     if (!points_fused(h) || !h->scale_init) {
         StageScope sc(h, SOSLAM_STAGE_POINT_REDUCE);
-        launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->C.p, h->gp.p);
+        launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->rows(), h->campre.p, h->C.p, h->gp.p);
         if (!h->scale_init) launch_point_scale(s, h->n_pt, h->C.p, h->opt.jacobi_scaling, h->sp.p);
         h->pt_blocks_valid = true;
     } else {
@@ -986,7 +987,7 @@ void run_schur(soslam_ba* h, const LmDiag& lm)
 {
     hipStream_t s = h->stream;
     launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pair_row.p, h->pt_obs.p, h->q_pt.p,
-                 h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p, h->scalp(),
+                 h->q_slot.p, h->rows(), h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p, h->scalp(),
                  h->pt_start.p, h->q_cam.p, h->pt_blocks_valid ? 0 : 1);
     h->pt_blocks_valid = true;
     launch_schur_long(s, h->n_long, h->long_pts.p, h->lo_row.p, h->lo_cam.p, h->lo_cam_off.p, h->n_long_pairs, h->pair_a.p, h->pair_b.p,
@@ -1194,11 +1195,11 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
         {
             StageScope sc(h, SOSLAM_STAGE_LINEARIZE);
             launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->cam_free.p, h->proj,
-                             h->opt.huber_delta, h->ar.p, h->tile_part.p, gate);
+                             h->opt.huber_delta, h->rows(), h->tile_part.p, gate);
         }
         if (!points_fused(h)) {
             StageScope sc(h, SOSLAM_STAGE_POINT_REDUCE);
-            launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre_c.p, h->C.p, h->gp.p, gate);
+            launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->rows(), h->campre_c.p, h->C.p, h->gp.p, gate);
         }
     }
     {
@@ -1977,18 +1978,18 @@ int soslam_ba_time_kernel(soslam_ba* h, int32_t kernel, int32_t reps, float* avg
         switch (kernel) {
         case SOSLAM_KERNEL_LINEARIZE:
             launch_linearize(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->cam_free.p,
-                             h->proj, h->opt.huber_delta, h->ar.p, h->tile_part.p);
+                             h->proj, h->opt.huber_delta, h->rows(), h->tile_part.p);
             break;
         case SOSLAM_KERNEL_COST:
             launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre.p, h->pts[h->cur].p, h->proj,
                         h->opt.huber_delta, h->cost_part.p);
             break;
         case SOSLAM_KERNEL_POINT_REDUCE:
-            launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->C.p, h->gp.p);
+            launch_point_reduce(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->rows(), h->campre.p, h->C.p, h->gp.p);
             break;
         case SOSLAM_KERNEL_SCHUR:
             launch_schur(s, h->kmax, h->n_chunks, h->chunks.p, h->batches.p, h->chunk_slab.p, h->chunk_cam.p, h->pair_row.p, h->pt_obs.p, h->q_pt.p,
-                         h->q_slot.p, h->ar.p, h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p,
+                         h->q_slot.p, h->rows(), h->campre.p, h->pts[h->cur].p, h->C.p, h->gp.p, h->sp.p, lm, h->Cinv.p, h->ptfac.p, h->slab.p,
                          h->scalp(), h->pt_start.p, h->q_cam.p, points_fused(h) ? 1 : 0);
             break;
         case SOSLAM_KERNEL_BACKSUB:
@@ -2072,7 +2073,10 @@ int soslam_ba_debug_read(soslam_ba* h, int32_t what, void* dst, uint64_t bytes)
         std::vector<double> tmp(n_obs * kArRow);
         SOSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->ar.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
         SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
-        for (size_t i = 0; i < n_obs; i++) std::memcpy(out + 9 * (size_t)h->obs_int2user[i], &tmp[i * kArRow], 9 * sizeof(double));
+        for (size_t i = 0; i < n_obs; i++) {   // [G (6) | h (3)] per observation from the two arrays (ba_kernels.h: CompactRows)
+            std::memcpy(out + 9 * (size_t)h->obs_int2user[i], &tmp[i * kArG], 6 * sizeof(double));
+            std::memcpy(out + 9 * (size_t)h->obs_int2user[i] + 6, &tmp[n_obs * kArG + i * kArH], 3 * sizeof(double));
+        }
         return SOSLAM_OK;
     }
     case SOSLAM_DBG_COST:
