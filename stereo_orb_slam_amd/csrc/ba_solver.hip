@@ -70,7 +70,26 @@ struct soslam_ba {
     int bw_full = 0;                    // the largest block offset when off_band
     double comp_share = 0.0;            // off_band: share of the left-out blocks' absolute row sums added to the factored diagonal
     int cr_rounds = 1;                  // PCG rounds enqueued per solve with the exact band factor (see take_step)
-    bool cr_factor_valid = false;       // cr_ws holds a factor of an earlier iteration's reduced matrix
+    bool cr_factor_valid = false;       // cr_ws_of(fac_idx) holds a complete factor of an earlier (or this) iteration's reduced matrix
+    // lagged factor (take_step): two workspaces, the refresh on a second stream
+    DevBuf<double> cr_ws2, lag_status;
+    hipStream_t fstream = nullptr;
+    hipEvent_t ev_s_ready = nullptr, ev_factor = nullptr;
+    int fac_idx = 0;                    // workspace of the newest complete factor
+    bool fac_pending = false;           // a refresh into the other workspace is in flight (ev_factor)
+    bool lag_ok = true;                 // the last lagged solve stayed within its rounds
+    bool lagged_solve = false;          // this iteration's solve used the lagged factor
+    int lag_rounds = 3;                 // PCG rounds enqueued with a lagged factor
+    double last_rel_decrease = 1.0;     // (cost - candidate) / cost of the last accepted step
+    double* cr_ws_of(int i) { return i == 0 ? cr_ws.p : cr_ws2.p; }
+    int lag_init()
+    {
+        if (fstream) return SOSLAM_OK;
+        SOSLAM_HIP_CHECK(hipStreamCreateWithFlags(&fstream, hipStreamNonBlocking));
+        SOSLAM_HIP_CHECK(hipEventCreateWithFlags(&ev_s_ready, hipEventDisableTiming));
+        SOSLAM_HIP_CHECK(hipEventCreateWithFlags(&ev_factor, hipEventDisableTiming));
+        return SOSLAM_OK;
+    }
     int solver = SOSLAM_SOLVER_PCG;
     double setup_seconds = 0.0;
 
@@ -170,6 +189,9 @@ struct soslam_ba {
         if (host_raw) (void)hipHostFree(host_raw);
         if (stage) (void)hipHostFree(stage);
         rccl_comm_destroy(rccl);
+        if (fstream) { (void)hipStreamSynchronize(fstream); (void)hipStreamDestroy(fstream); }
+        if (ev_s_ready) (void)hipEventDestroy(ev_s_ready);
+        if (ev_factor) (void)hipEventDestroy(ev_factor);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -263,6 +285,9 @@ void parallel_ranges(size_t n, size_t work, F&& f)
 int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, const uint32_t* ocam,
                   const uint32_t* opt_, const float* ouv, const uint8_t* fixed)
 {
+    if (h->fstream) SOSLAM_HIP_CHECK(hipStreamSynchronize(h->fstream));   // a refresh of the lagged factor may still read S and write a workspace
+    h->fac_pending = false;
+
     const double t0 = now_sec();
     const bool setup_timing = std::getenv("SOSLAM_SETUP_TIMING") != nullptr;
     double t_mark = t0;
@@ -821,6 +846,11 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
                 std::getenv("SOSLAM_NO_CR") == nullptr;
     if (h->use_cr) {
         SOSLAM_CHECK(h->cr_ws.alloc(cr_count(nf, h->bw)));
+        SOSLAM_CHECK(h->cr_ws2.alloc(cr_count(nf, h->bw)));
+        SOSLAM_CHECK(h->lag_status.alloc(SC_COUNT + 8));
+        SOSLAM_CHECK(h->lag_status.zero(s));
+        SOSLAM_CHECK(h->lag_init());   // the second stream and its events: set-up time, not solve time
+        h->fac_idx = 0; h->fac_pending = false; h->lag_ok = true; h->lag_rounds = 3; h->last_rel_decrease = 1.0;
         std::vector<int32_t> map(cr_map_count(nf, h->bw));
         cr_build_map(nf, h->bw, h->n_blocks, h->h_blk_row.data(), h->h_blk_col.data(), map.data());
         SOSLAM_CHECK(h->cr_map.upload(map, s));
@@ -1031,6 +1061,13 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
     {
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
         run_schur(h, lm);
+        if (h->fac_pending) {
+            // the refresh of the lagged factor (second stream) reads S and writes the other workspace: S is rewritten below,
+            // and from here on that workspace is the newest factor
+            SOSLAM_HIP_CHECK(hipStreamWaitEvent(s, h->ev_factor, 0));
+            h->fac_pending = false;
+            h->fac_idx ^= 1;
+        }
         launch_schur_reduce(s, h->n_blocks, h->n_free, h->blk_contrib_ptr.p, h->blk_contrib_off.p, h->cam_contrib_ptr.p,
                             h->cam_contrib_off.p, h->blk_row.p, h->blk_col.p, h->free_cam.p, h->campre.p, h->slab.p, h->cam_tile_start.p, h->tile_part.p,
                             h->S(), h->rhs(), h->diagB(), h->gc_red(), h->scalp() + SC_COST_X, h->tail());
@@ -1067,21 +1104,35 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                 launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp, nullptr, h->rhs());
                 launch_cr_solve(s, h->n_free, h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, nullptr, true);
             } else if (h->use_cr && h->pcg_band) {
-                static const char* const lag_env = std::getenv("SOSLAM_CR_LAG");           // EXPERIMENT: one-iteration-old factor
-                static const double lag_pred = std::getenv("SOSLAM_CR_LAG_PRED") ? std::atof(std::getenv("SOSLAM_CR_LAG_PRED")) : 3.0;
-                static const int lag_rounds = std::getenv("SOSLAM_CR_LAG_ROUNDS") ? std::atoi(std::getenv("SOSLAM_CR_LAG_ROUNDS")) : 8;
-                if (lag_env && lag_env[0] == '1') {
+                // LAGGED FACTOR.  Once the iterates have all but converged (the last accepted step lowered the cost by less than
+                // 1e-7 of it) S hardly moves from one linearisation to the next, and the factor of the PREVIOUS reduced matrix is
+                // a preconditioner that takes PCG to the tolerance in two or three rounds (measured, configs[2]: 8 rounds and more
+                // during the first twelve iterations, 3 from the thirteenth, 2 from the sixteenth).  A round is 54 us, the
+                // factorisation 170: so in that phase this iteration's factorisation leaves the critical path - it runs on a
+                // second stream beside the rest of the iteration, for the NEXT solve - and the solve is the PCG alone.  Early
+                // iterations, rejected or invalid steps and anything that made the last lagged solve take more than four rounds
+                // get a fresh factor as before.
+                static const bool lag_off = std::getenv("SOSLAM_NO_LAG") != nullptr;
+                const bool use_lag = !lag_off && !h->off_band && h->cr_factor_valid && h->lag_ok && h->last_rel_decrease < 1e-7;
+                if (use_lag) {
+                    double* ws_old = h->cr_ws_of(h->fac_idx);
+                    double* ws_new = h->cr_ws_of(h->fac_idx ^ 1);
                     launch_cam_damp(s, h->n_free, h->diagB(), h->sc.p, damp.init_scale, h->opt.jacobi_scaling, lm, h->diag_block.p, h->S(), h->lc.p);
-                    const LmDiag lmf = lm_diag(h, std::min(h->opt.max_radius, radius * lag_pred));
-                    const CrShift shift{h->diagB(), h->sc.p, h->lc.p, lmf, h->n_free};
-                    if (!h->cr_factor_valid) launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), nullptr, nullptr);
-                    launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
-                                  h->opt.pcg_tolerance, h->cr_factor_valid ? lag_rounds : 2, h->scalp());
-                    launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), nullptr, &shift);
-                    h->cr_factor_valid = true;
+                    // the refresh, off the critical path: S (damped) is complete here; nothing writes it again before the next
+                    // iteration's ba_schur_reduce, which waits for ev_factor (take_step, above)
+                    SOSLAM_CHECK(h->lag_init());
+                    SOSLAM_HIP_CHECK(hipEventRecord(h->ev_s_ready, s));
+                    SOSLAM_HIP_CHECK(hipStreamWaitEvent(h->fstream, h->ev_s_ready, 0));
+                    launch_cr_factor(h->fstream, bsr_view(h), h->cr_map.p, h->bw, ws_new, h->lag_status.p, nullptr, nullptr, nullptr);
+                    SOSLAM_HIP_CHECK(hipEventRecord(h->ev_factor, h->fstream));
+                    h->fac_pending = true;
+                    launch_pcg_cr(s, bsr_view(h), h->bw, ws_old, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance,
+                                  std::min(h->opt.pcg_max_iterations, h->lag_rounds), h->scalp(), false);
+                    h->lagged_solve = true;
                 } else {
+                h->lagged_solve = false;
                 if (!h->off_band) {
-                    launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp, nullptr, h->rhs());
+                    launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws_of(h->fac_idx), h->scalp(), &damp, nullptr, h->rhs());
                 } else {
                     // The factored band leaves blocks of S out, and the band part of a positive definite matrix need not be
                     // positive definite.  A breakdown must not become an invalid LM step (the reference's direct solver has
@@ -1090,7 +1141,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                     // following iterations; at share 1 the factored matrix is positive definite whatever was left out).
                     launch_cr_comp(s, h->S(), h->n_free, h->cr_comp_ptr.p, h->cr_comp_ent.p, h->cr_comp.p);
                     for (int attempt = 0; attempt < 6; attempt++) {
-                        launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), attempt == 0 ? &damp : nullptr, nullptr,
+                        launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws_of(h->fac_idx), h->scalp(), attempt == 0 ? &damp : nullptr, nullptr,
                                          h->rhs(), h->cr_comp.p, h->comp_share);
                         double st = 0.0;
                         SOSLAM_HIP_CHECK(hipMemcpyAsync(&st, h->scalp() + SC_LIN_STATUS, sizeof st, hipMemcpyDeviceToHost, s));
@@ -1100,8 +1151,9 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                         h->comp_share = h->comp_share == 0.0 ? 0.125 : std::min(1.0, 2.0 * h->comp_share);
                     }
                 }
-                launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
+                launch_pcg_cr(s, bsr_view(h), h->bw, h->cr_ws_of(h->fac_idx), h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
                               h->opt.pcg_tolerance, std::min(h->opt.pcg_max_iterations, h->cr_rounds), h->scalp(), true);
+                h->cr_factor_valid = true;
                 if (h->off_band) {
                     // this mode synchronises anyway (above): the solve runs to its tolerance here, in chunks of as many rounds as
                     // the last solve used, instead of handing an unconverged step to the LM loop
@@ -1112,7 +1164,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                         SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
                         if (lin[1] <= h->opt.pcg_tolerance || lin[2] != 0.0) break;
                         const int more = std::min(h->opt.pcg_max_iterations - enq, std::max(4, enq / 2));
-                        launch_pcg_cr_more(s, bsr_view(h), h->bw, h->cr_ws.p, h->dc_free.p, h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance, more,
+                        launch_pcg_cr_more(s, bsr_view(h), h->bw, h->cr_ws_of(h->fac_idx), h->dc_free.p, h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance, more,
                                            h->scalp());
                         enq += more;
                     }
@@ -1222,7 +1274,14 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
     }
     // With blocks outside the factored band (off_band) the factor is a preconditioner proper: more rounds, found the same way
     // (twice as many after a solve that fell short, as many as were used after one that did not need them all).
-    if (h->use_cr && h->pcg_band && h->n_free) {
+    if (h->use_cr && h->pcg_band && h->n_free && h->lagged_solve) {
+        // rounds of the lagged solve: as many as it used, one more after a solve that fell short; a solve that needed more than
+        // four sends the next iteration back to a fresh factor
+        const int used = (int)h->host_scal[SC_LIN_ITERS];
+        if (h->host_scal[SC_LIN_RESID] > h->opt.pcg_tolerance) { h->lag_rounds = std::min(h->lag_rounds + 1, 6); h->lag_ok = h->lag_rounds <= 4; }
+        else h->lag_rounds = std::max(2, used);
+    } else if (h->use_cr && h->pcg_band && h->n_free) {
+        h->lag_ok = true;
         const int used = (int)h->host_scal[SC_LIN_ITERS];
         const int cap = h->off_band ? h->opt.pcg_max_iterations : 4;
         if (h->off_band) h->cr_rounds = std::max(2, std::min(used + 1, cap));   // the solve ran to its tolerance (take_step): one spare round
@@ -1548,6 +1607,8 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         if (!lin_ok || !(sc.mcc > 0.0)) {
             e.valid = 0;
             h->log.push_back(e);
+            h->last_rel_decrease = 1.0;
+            h->cr_factor_valid = false;   // whatever broke this solve must not precondition the next one
             if (check && ++h->invalid_run >= 5) { sum.termination = SOSLAM_TERM_INVALID_STEPS; break; }
             // Ceres: TrustRegionMinimizer::HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid halves the radius
             // and leaves the rejected-step factor alone (a later rejection still divides by the factor it would have used)
@@ -1584,7 +1645,9 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
         }
         const double rel = (sc.x_cost - sc.cand_cost) / sc.mcc;
         e.relative_decrease = rel;
+        h->last_rel_decrease = 1.0;   // a rejected step: the next solve gets a fresh factor (take_step: lagged factor)
         if (rel > o.min_relative_decrease) {
+            h->last_rel_decrease = sc.x_cost > 0.0 ? (sc.x_cost - sc.cand_cost) / sc.x_cost : 1.0;
             h->cur ^= 1;
             h->campre.swap(h->campre_c);   // the candidate's table becomes the linearisation point's
             h->campre_current = true;
@@ -1772,6 +1835,7 @@ int soslam_ba_set_state(soslam_ba* h, const double* poses, const double* points)
     SOSLAM_HIP_CHECK(hipMemcpyAsync(h->cams[0].p, poses, sizeof(double) * 6 * h->n_cam, hipMemcpyHostToDevice, h->stream));
     if (h->n_pt) SOSLAM_HIP_CHECK(hipMemcpyAsync(h->pts[0].p, p.data(), sizeof(double) * p.size(), hipMemcpyHostToDevice, h->stream));
     SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->last_rel_decrease = 1.0;   // a new starting point: the first solve factors afresh
     h->radius = h->opt.initial_radius;
     h->decrease_factor = 2.0;
     h->invalid_run = 0;
