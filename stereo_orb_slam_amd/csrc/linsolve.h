@@ -146,12 +146,17 @@ struct TwoLevelView {
     uint32_t ncp;                // coarse dimension padded to a multiple of 60 (launch_dense_spd_inverse60), <= 1260
     const uint32_t* agg_ptr;     // [n_agg + 1] first block row of every aggregate
     const double* P;             // [n_rows][36] row-major: the block row's increment per coarse unknown of its aggregate
-    const double* Ainv;          // [ncp * ncp] (P^T (A + shift I) P)^-1, written by pcg2_solve
+    const double* Ainv;          // [ncp * ncp] the coarse operator (pcg2_coarse_inverse)
     double* rc;                  // [ncp] P^T r (entries from 6 n_agg on stay zero)
 };
 size_t pcg2_work_count(uint32_t n_rows, uint32_t n_agg);
-// as pcg_multi_solve; Ac0 = P^T A P ([ncp * ncp], without the shift), G = P^T P per aggregate ([n_agg][36]), ebuf 2 x 3600 f64
+// the coarse operator (P^T A P + shift P^T P)^-1 into ainv_out: Ac0 = P^T A P ([ncp * ncp], without the shift), G = P^T P per
+// aggregate ([n_agg][36]), ebuf 2 x 3600 f64 of scratch, status[0] = 1 on a non-positive pivot tile.  Any symmetric positive
+// definite coarse operator makes a valid preconditioner: the caller may hand pcg2_solve the inverse of an EARLIER matrix.
+void pcg2_coarse_inverse(hipStream_t s, uint32_t n_agg, uint32_t ncp, const double* Ac0, const double* G, double shift, double* ainv_out,
+                         double* ebuf, double* status);
+// as pcg_multi_solve, preconditioner D^-1 + P tl.Ainv P^T
 int pcg2_solve(hipStream_t s, const BsrView& A, double shift, const double* b, double* x, double* resid, double* work, const TwoLevelView& tl,
-               const double* Ac0, const double* G, double* ebuf, double tol, int max_iter, int chunk, double* rel_resid);
+               double tol, int max_iter, int chunk, double* rel_resid);
 
 }  // namespace soslam

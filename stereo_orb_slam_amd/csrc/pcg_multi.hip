@@ -537,8 +537,18 @@ size_t pcg2_work_count(uint32_t n_rows, uint32_t n_agg)
     return 4 * n + 36 * (size_t)n_rows + 5 * (size_t)n_agg + ST_COUNT + 16;
 }
 
+// the coarse operator for a shift: (P^T A P + shift P^T P)^-1, explicit, into ainv_out ([ncp * ncp]); status[0] = 1 on a
+// non-positive pivot tile.  Its own call so that the caller may run it on another stream for a LATER solve (pg_solver.hip).
+void pcg2_coarse_inverse(hipStream_t s, uint32_t n_agg, uint32_t ncp, const double* Ac0, const double* G, double shift, double* ainv_out,
+                         double* ebuf, double* status)
+{
+    if (!n_agg) return;
+    hipLaunchKernelGGL(pcg2_coarse_matrix_kernel, dim3(ncp), dim3(256), 0, s, Ac0, G, shift, n_agg * 6, ncp, ainv_out);
+    launch_dense_spd_inverse60(s, ainv_out, (int)(ncp / 60), ebuf, status);
+}
+
 int pcg2_solve(hipStream_t s, const BsrView& A, double shift, const double* b, double* x, double* resid, double* work, const TwoLevelView& tl,
-               const double* Ac0, const double* G, double* ebuf, double tol, int max_iter, int chunk, double* rel_resid)
+               double tol, int max_iter, int chunk, double* rel_resid)
 {
     if (rel_resid) *rel_resid = 0.0;
     if (!A.n_rows) return 0;
@@ -553,9 +563,6 @@ int pcg2_solve(hipStream_t s, const BsrView& A, double shift, const double* b, d
     w.state = w.part_rr + 2 * (size_t)n_wg;
     double* r = resid;
     (void)hipMemsetAsync(w.state, 0, sizeof(double) * ST_COUNT, s);
-    // the coarse operator for this shift: (P^T A P + shift P^T P)^-1, explicit
-    hipLaunchKernelGGL(pcg2_coarse_matrix_kernel, dim3(tl.ncp), dim3(256), 0, s, Ac0, G, shift, tl.n_agg * 6, tl.ncp, const_cast<double*>(tl.Ainv));
-    launch_dense_spd_inverse60(s, const_cast<double*>(tl.Ainv), (int)(tl.ncp / 60), ebuf, w.state + ST_BREAKDOWN);
     hipLaunchKernelGGL(pcg2_init_kernel, dim3(n_wg), dim3(kThreads), 0, s, A, shift, b, x, r, w, tl);
     hipLaunchKernelGGL(pcgm_bb_kernel, dim3(1), dim3(64), 0, s, PcgBufs{{w.p[0], w.p[1]}, w.z, w.q, w.minv, w.part_pq, w.part_rz, w.part_rr, w.state, w.n_wg});
     hipLaunchKernelGGL(pcg2_coarse_kernel<true>, dim3(n_wg), dim3(kThreads), 0, s, r, w, tl, 0, tol);

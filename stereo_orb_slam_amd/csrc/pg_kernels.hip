@@ -374,39 +374,54 @@ __global__ __launch_bounds__(64) void pg_coarse_gram_kernel(const uint32_t* __re
     G[36 * (size_t)I + e] = s;
 }
 
-// one coarse block (I, J) of P^T H P: the sum over its fine blocks, in list order (entry = 2 * block + swap; swap: the stored
-// block is H(i, j) with i in J and j in I, so its transpose is what couples I to J).  One wave per coarse block.
-__global__ __launch_bounds__(64) void pg_coarse_assemble_kernel(const uint32_t* __restrict__ cb_ptr, const uint32_t* __restrict__ cb_ent,
-                                                                const uint32_t* __restrict__ cb_I, const uint32_t* __restrict__ cb_J,
-                                                                const uint32_t* __restrict__ blk_row, const uint32_t* __restrict__ blk_col,
-                                                                const double* __restrict__ H, const double* __restrict__ P, const uint32_t ncp,
-                                                                double* __restrict__ Ac0)
+// one coarse block (I, J) of P^T H P: the sum over its fine blocks (entry = 2 * block + swap; swap: the stored block is H(i, j)
+// with i in J and j in I, so its transpose is what couples I to J).  One workgroup per coarse block: seven groups of 36 lanes take
+// every seventh fine block of the list, their partial sums are added in group order (fixed order: reproducible).
+constexpr int kAsmGroups = 7;
+__global__ __launch_bounds__(256) void pg_coarse_assemble_kernel(const uint32_t* __restrict__ cb_ptr, const uint32_t* __restrict__ cb_ent,
+                                                                 const uint32_t* __restrict__ cb_I, const uint32_t* __restrict__ cb_J,
+                                                                 const uint32_t* __restrict__ blk_row, const uint32_t* __restrict__ blk_col,
+                                                                 const double* __restrict__ H, const double* __restrict__ P, const uint32_t ncp,
+                                                                 double* __restrict__ Ac0)
 {
-    __shared__ double T[36];
+    __shared__ double T[kAsmGroups][36];
+    __shared__ double part[kAsmGroups][36];
     const uint32_t cb = blockIdx.x;
-    const int e = threadIdx.x, a = e / 6, b = e % 6;
+    const int grp = threadIdx.x / 36, e = threadIdx.x % 36, a = e / 6, b = e % 6;
+    const bool on = grp < kAsmGroups;
     double acc = 0.0;
-    for (uint32_t q = cb_ptr[cb]; q < cb_ptr[cb + 1]; q++) {
-        const uint32_t blk = cb_ent[q] >> 1, swap = cb_ent[q] & 1;
-        const uint32_t i = blk_row[blk], j = blk_col[blk];
-        const double* Hb = H + 36 * (size_t)blk;
-        const double* L = P + 36 * (size_t)(swap ? j : i);
-        const double* Rr = P + 36 * (size_t)(swap ? i : j);
-        // T = Hm Rr with Hm = Hb or Hb^T
-        if (e < 36) {
-            double t = 0.0;
+    const uint32_t q0 = cb_ptr[cb], q1 = cb_ptr[cb + 1];
+    // uniform trip count: every lane reaches the barriers
+    for (uint32_t base = q0; base < q1; base += kAsmGroups) {
+        const uint32_t q = base + (uint32_t)grp;
+        const bool live = on && q < q1;
+        const double* L = nullptr;
+        if (live) {
+            const uint32_t blk = cb_ent[q] >> 1, swap = cb_ent[q] & 1;
+            const uint32_t i = blk_row[blk], j = blk_col[blk];
+            const double* Hb = H + 36 * (size_t)blk;
+            L = P + 36 * (size_t)(swap ? j : i);
+            const double* Rr = P + 36 * (size_t)(swap ? i : j);
+            double t = 0.0;   // T = Hm Rr with Hm = Hb or Hb^T
 #pragma unroll
             for (int d = 0; d < 6; d++) t += (swap ? Hb[d * 6 + a] : Hb[a * 6 + d]) * Rr[d * 6 + b];
-            T[e] = t;
+            T[grp][e] = t;
         }
         __syncthreads();
-        if (e < 36) {
+        if (live) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) acc += L[c * 6 + a] * T[c * 6 + b];
+            for (int c = 0; c < 6; c++) acc += L[c * 6 + a] * T[grp][c * 6 + b];
         }
         __syncthreads();
     }
-    if (e < 36) Ac0[(size_t)(6 * cb_I[cb] + a) * ncp + 6 * cb_J[cb] + b] = acc;
+    if (on) part[grp][e] = acc;
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        double sum = 0.0;
+#pragma unroll
+        for (int g = 0; g < kAsmGroups; g++) sum += part[g][threadIdx.x];
+        Ac0[(size_t)(6 * cb_I[cb] + a) * ncp + 6 * cb_J[cb] + b] = sum;
+    }
 }
 
 }  // namespace
@@ -457,7 +472,7 @@ void launch_pg_coarse_setup(hipStream_t s, uint32_t n_free, uint32_t n_agg, cons
     hipLaunchKernelGGL(pg_coarse_basis_kernel, dim3((n_free + 255) / 256), dim3(256), 0, s, n_free, free_vertex, row_agg, agg_ref, est, P);
     hipLaunchKernelGGL(pg_coarse_gram_kernel, dim3(n_agg), dim3(64), 0, s, agg_ptr, P, G);
     (void)hipMemsetAsync(Ac0, 0, sizeof(double) * (size_t)ncp * ncp, s);
-    if (n_cb) hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3(n_cb), dim3(64), 0, s, cb_ptr, cb_ent, cb_I, cb_J, blk_row, blk_col, H, P, ncp, Ac0);
+    if (n_cb) hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3(n_cb), dim3(256), 0, s, cb_ptr, cb_ent, cb_I, cb_J, blk_row, blk_col, H, P, ncp, Ac0);
 }
 
 }  // namespace soslam

@@ -39,7 +39,13 @@ struct soslam_pg {
     int last_lin_it = 0;                // PCG iterations of the last solve: the next solve enqueues that many before it looks
     uint32_t n_agg = 0, ncp = 0, n_cb = 0;
     DevBuf<uint32_t> agg_ptr, row_agg, agg_ref, free_vertex, cb_ptr, cb_ent, cb_I, cb_J;
-    DevBuf<double> cP, cG, cAc0, cAinv, cebuf, crc;
+    DevBuf<double> cP, cG, cAc0, cAinv[2], cebuf[2], crc, cstatus;
+    // the coarse inverse of a Levenberg trial is computed on a second stream while that trial's PCG runs with the previous one
+    // (any SPD coarse operator preconditions): cinv_cur holds the newest complete one
+    hipStream_t cstream = nullptr;
+    hipEvent_t ev_coarse_in = nullptr, ev_coarse_done = nullptr;
+    int cinv_cur = 0;
+    bool cinv_valid = false, cinv_pending = false;
     int cur = 0;
     double setup_seconds = 0.0;
     std::vector<soslam_pg_iteration> log;
@@ -48,6 +54,9 @@ struct soslam_pg {
     ~soslam_pg()
     {
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
+        if (cstream) { (void)hipStreamSynchronize(cstream); (void)hipStreamDestroy(cstream); }
+        if (ev_coarse_in) (void)hipEventDestroy(ev_coarse_in);
+        if (ev_coarse_done) (void)hipEventDestroy(ev_coarse_done);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -289,8 +298,19 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
         SOSLAM_CHECK(h->cP.alloc((size_t)nf * 36));
         SOSLAM_CHECK(h->cG.alloc((size_t)h->n_agg * 36));
         SOSLAM_CHECK(h->cAc0.alloc((size_t)h->ncp * h->ncp));
-        SOSLAM_CHECK(h->cAinv.alloc((size_t)h->ncp * h->ncp));
-        SOSLAM_CHECK(h->cebuf.alloc(2 * 3600));
+        if (h->cstream) SOSLAM_HIP_CHECK(hipStreamSynchronize(h->cstream));
+        else {
+            SOSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+            SOSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_coarse_in, hipEventDisableTiming));
+            SOSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_coarse_done, hipEventDisableTiming));
+        }
+        h->cinv_valid = false; h->cinv_pending = false; h->cinv_cur = 0;
+        for (int q = 0; q < 2; q++) {
+            SOSLAM_CHECK(h->cAinv[q].alloc((size_t)h->ncp * h->ncp));
+            SOSLAM_CHECK(h->cebuf[q].alloc(2 * 3600));
+        }
+        SOSLAM_CHECK(h->cstatus.alloc(8));
+        SOSLAM_CHECK(h->cstatus.zero(s));
         SOSLAM_CHECK(h->crc.alloc(h->ncp));
         SOSLAM_CHECK(h->crc.zero(s));
     }
@@ -320,6 +340,12 @@ int linearize(soslam_pg* h, double* dbg_e, double* dbg_ji, double* dbg_jj)
                         h->chi_part_lin.p, dbg_e, dbg_ji, dbg_jj);
     launch_pg_gather(s, h->n_blocks, h->g_ptr.p, h->g_ent.p, h->blk_row.p, h->blk_col.p, h->econ.p, h->H.p, h->b.p);
     launch_pg_reduce(s, h->chi_part_lin.p, h->n_chi_part, h->H.p, h->diag_block.p, h->n_free, h->scal.p);
+    if (h->two_level && h->cinv_pending) {
+        // the coarse inverse under way on the second stream read Ac0 and G: they are rewritten below
+        SOSLAM_HIP_CHECK(hipStreamWaitEvent(s, h->ev_coarse_done, 0));
+        h->cinv_pending = false;
+        h->cinv_cur ^= 1;
+    }
     if (h->two_level)
         launch_pg_coarse_setup(s, h->n_free, h->n_agg, h->free_vertex.p, h->row_agg.p, h->agg_ref.p, h->agg_ptr.p, h->est[h->cur].p, h->n_cb,
                                h->cb_ptr.p, h->cb_ent.p, h->cb_I.p, h->cb_J.p, h->blk_row.p, h->blk_col.p, h->H.p, h->ncp, h->cP.p, h->cG.p, h->cAc0.p);
@@ -375,8 +401,27 @@ int run(soslam_pg* h, soslam_pg_summary* out)
             int lin_it = 0;
             SOSLAM_HIP_CHECK(hipEventRecord(h->ev[0], s));
             if (h->n_free && h->two_level) {
-                const TwoLevelView tl{h->n_agg, h->ncp, h->agg_ptr.p, h->cP.p, h->cAinv.p, h->crc.p};
-                lin_it = pcg2_solve(s, bsr_view(h), lambda, h->b.p, h->x.p, h->resid.p, h->work.p, tl, h->cAc0.p, h->cG.p, h->cebuf.p, o.pcg_tolerance,
+                if (h->cinv_pending) {   // a second trial of the same iteration: the inverse the first one started
+                    SOSLAM_HIP_CHECK(hipStreamWaitEvent(s, h->ev_coarse_done, 0));
+                    h->cinv_pending = false;
+                    h->cinv_cur ^= 1;
+                }
+                if (!h->cinv_valid) {
+                    // the first solve of a graph: nothing to lag behind
+                    pcg2_coarse_inverse(s, h->n_agg, h->ncp, h->cAc0.p, h->cG.p, lambda, h->cAinv[h->cinv_cur].p, h->cebuf[h->cinv_cur].p, h->cstatus.p);
+                    h->cinv_valid = true;
+                } else {
+                    // this trial's coarse inverse, for the NEXT solve, beside this solve (0.4 - 0.7 ms of small launches that would
+                    // otherwise sit in front of every PCG)
+                    const int other = h->cinv_cur ^ 1;
+                    SOSLAM_HIP_CHECK(hipEventRecord(h->ev_coarse_in, s));
+                    SOSLAM_HIP_CHECK(hipStreamWaitEvent(h->cstream, h->ev_coarse_in, 0));
+                    pcg2_coarse_inverse(h->cstream, h->n_agg, h->ncp, h->cAc0.p, h->cG.p, lambda, h->cAinv[other].p, h->cebuf[other].p, h->cstatus.p);
+                    SOSLAM_HIP_CHECK(hipEventRecord(h->ev_coarse_done, h->cstream));
+                    h->cinv_pending = true;
+                }
+                const TwoLevelView tl{h->n_agg, h->ncp, h->agg_ptr.p, h->cP.p, h->cAinv[h->cinv_cur].p, h->crc.p};
+                lin_it = pcg2_solve(s, bsr_view(h), lambda, h->b.p, h->x.p, h->resid.p, h->work.p, tl, o.pcg_tolerance,
                                     o.pcg_max_iterations, h->last_lin_it > 0 ? h->last_lin_it + 2 : 48, &rel);
                 if (lin_it > 0) h->last_lin_it = lin_it;
             } else if (h->n_free) {
