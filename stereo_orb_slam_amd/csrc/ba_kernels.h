@@ -96,16 +96,9 @@ struct CamDamp {
     uint32_t n_free;
 };
 
-// The cyclic-reduction gather for a factor that is to serve a LATER solve as its preconditioner: S carries the damping lc
-// of the current radius, the factor is made for the radius in lm (the one the next iteration is expected to use); the
-// difference goes onto the diagonal of the gathered super-blocks only.
-struct CrShift {
-    const double* diagB;   // nullptr: no shift
-    const double* sc;
-    const double* lc;
-    LmDiag lm;
-    uint32_t n_free;
-};
+// coarse basis of the two-level PCG (free camera f: row f of P, 36 f64), aggregates given by row_agg / agg_ref (a camera index)
+void launch_ba_coarse_basis(hipStream_t s, uint32_t n_free, const uint32_t* free_cam, const uint32_t* row_agg, const uint32_t* agg_ref,
+                            const double* campre, double* P);
 
 // campre[n_cam][kPoseStride]: per-camera rotation block consumed by launch_linearize / launch_cost
 void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, double* campre);

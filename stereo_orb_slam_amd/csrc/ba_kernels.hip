@@ -1614,9 +1614,62 @@ __global__ __launch_bounds__(kPointBlock) void ba_backsub_kernel(
     }
 }
 
+
+// ---- coarse basis of the two-level PCG (pcg_multi.hip: pcg2_solve) for reduced camera systems no band factor applies to --------
+// The weak directions of S are the drift modes of the chain: whole stretches of cameras (with their points) moved rigidly cost
+// next to nothing.  P_c (6 x 6, row-major; rows [dw (3) | dt (3)], columns [v (3) | theta (3)]) is camera c's parameter change
+// under a rigid motion x -> x + theta x (x - a) + v of its aggregate's share of the world (a = the centre of the aggregate's
+// reference camera):  R' = R (I - [theta]x)  =>  dw = -M^-1 R theta  (d(R x)/dw = -[R x]x M, M of the pose table),
+// dt = -R v - R [a]x theta.
+__global__ __launch_bounds__(256) void ba_coarse_basis_kernel(const uint32_t n_free, const uint32_t* __restrict__ free_cam,
+                                                              const uint32_t* __restrict__ row_agg, const uint32_t* __restrict__ agg_ref,
+                                                              const double* __restrict__ campre, double* __restrict__ P)
+{
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_free) return;
+    const double* pc = campre + kPoseStride * (size_t)free_cam[f];
+    const double* pr = campre + kPoseStride * (size_t)agg_ref[row_agg[f]];
+    double R[9], M[9], a[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { R[i] = pc[i]; M[i] = pc[9 + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) a[i] = -(pr[i] * pr[18] + pr[3 + i] * pr[19] + pr[6 + i] * pr[20]);   // -R_ref^T t_ref
+    // M^-1 by the adjugate (M = R Jr: well conditioned away from |w| = 2 pi)
+    double Mi[9];
+    {
+        const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+        const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+        const double id = 1.0 / det;
+        Mi[0] = c00 * id; Mi[1] = (M[2] * M[7] - M[1] * M[8]) * id; Mi[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+        Mi[3] = c01 * id; Mi[4] = (M[0] * M[8] - M[2] * M[6]) * id; Mi[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+        Mi[6] = c02 * id; Mi[7] = (M[1] * M[6] - M[0] * M[7]) * id; Mi[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+    }
+    const double ax[9] = {0.0, -a[2], a[1], a[2], 0.0, -a[0], -a[1], a[0], 0.0};
+    double* Pc = P + 36 * (size_t)f;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double mr = 0.0, ra = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { mr += Mi[i * 3 + k] * R[k * 3 + j]; ra += R[i * 3 + k] * ax[k * 3 + j]; }
+            Pc[i * 6 + j] = 0.0;
+            Pc[i * 6 + 3 + j] = -mr;
+            Pc[(3 + i) * 6 + j] = -R[i * 3 + j];
+            Pc[(3 + i) * 6 + 3 + j] = -ra;
+        }
+}
+
 }  // namespace
 
 // ---- launch wrappers --------------------------------------------------------------------------------
+
+void launch_ba_coarse_basis(hipStream_t s, uint32_t n_free, const uint32_t* free_cam, const uint32_t* row_agg, const uint32_t* agg_ref,
+                            const double* campre, double* P)
+{
+    if (!n_free) return;
+    hipLaunchKernelGGL(ba_coarse_basis_kernel, dim3((n_free + 255) / 256), dim3(256), 0, s, n_free, free_cam, row_agg, agg_ref, campre, P);
+}
 
 void launch_pose_prepare(hipStream_t s, uint32_t n_cam, const double* cams, double* campre)
 {

@@ -44,6 +44,7 @@ double now_sec()
 }
 
 constexpr int kDenseAutoLimit = 1200;   // camera dof up to which AUTO picks the dense Cholesky
+constexpr uint32_t kPcgMultiMinRows = 64;   // below this one workgroup does a whole PCG iteration faster than three launches
 
 }  // namespace
 
@@ -69,6 +70,13 @@ struct soslam_ba {
     bool off_band = false;              // some blocks of S lie outside the factored band bw (loop closures): they stay in the matvec only
     int bw_full = 0;                    // the largest block offset when off_band
     double comp_share = 0.0;            // off_band: share of the left-out blocks' absolute row sums added to the factored diagonal
+    // two-level PCG (pcg_multi.hip: pcg2_solve) for reduced systems no band factor applies to: aggregates of consecutive free
+    // cameras x six rigid-body modes (ba_coarse_basis_kernel)
+    bool two_level = false;
+    uint32_t tl_n_agg = 0, tl_ncp = 0, tl_n_cb = 0;
+    int tl_last_it = 0;
+    DevBuf<uint32_t> tl_agg_ptr, tl_row_agg, tl_agg_ref, tl_cb_ptr, tl_cb_ent, tl_cb_I, tl_cb_J;
+    DevBuf<double> tl_P, tl_G, tl_Ac0, tl_Ainv, tl_ebuf, tl_rc, tl_status;
     int cr_rounds = 1;                  // PCG rounds enqueued per solve with the exact band factor (see take_step)
     bool cr_factor_valid = false;       // cr_ws_of(fac_idx) holds a complete factor of an earlier (or this) iteration's reduced matrix
     // lagged factor (take_step): two workspaces, the refresh on a second stream
@@ -743,7 +751,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         // damping is small, and the diagonal compensation that restores it (take_step) stiffens the smooth modes - measured
         // (scripts/offband_probe.py): 120 cameras with 10 % of tracks of length 20: 480 rounds against block-Jacobi's 340 much
         // cheaper iterations; 150 cameras, tracks of 24: 340 against 180.  Such problems keep the block-Jacobi PCG.
-        if (w > kCrBandMax) w = 0;
+        if (w > kCrBandMax) w = std::getenv("SOSLAM_FORCE_OFFBAND") ? kCrBandMax : 0;   // (the switch: development, scripts/wideband_parity_probe.py)
         if (w >= 1 && std::getenv("SOSLAM_NO_CR") == nullptr && std::getenv("SOSLAM_NO_OFFBAND") == nullptr &&
             h->opt.linear_solver != SOSLAM_SOLVER_BAND_CHOLESKY &&
             h->opt.linear_solver != SOSLAM_SOLVER_DENSE_CHOLESKY && !(h->opt.linear_solver == SOSLAM_SOLVER_AUTO && nf * 6 <= (uint32_t)kDenseAutoLimit)) {
@@ -872,6 +880,47 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         h->band.release();
         h->bandT.release();
         h->band_dinv.release();
+    }
+    // Two-level PCG where block-Jacobi PCG would run: the band is wider than either band factor takes, or more than 1 % of the
+    // blocks lie outside it.  The weak directions of S on a camera chain are its drift modes - rigid motions of whole stretches
+    // of cameras - which block-Jacobi sees one camera at a time (400 - 500 iterations on configs[2] with 10 % of tracks of length
+    // 20); six rigid-body modes per aggregate of consecutive free cameras span them.
+    h->two_level = h->solver == SOSLAM_SOLVER_PCG && !h->pcg_band && nf >= kPcgMultiMinRows && std::getenv("SOSLAM_NO_TWO_LEVEL") == nullptr;
+    if (h->two_level) {
+        const uint32_t per = std::max<uint32_t>(12, (nf + 199) / 200);   // cameras per aggregate: at most 200 aggregates (1 200 coarse unknowns)
+        if (per > 42) h->two_level = false;                              // one workgroup of pcg2 per aggregate: 42 block rows
+        else {
+            std::vector<uint32_t> agg_ptr{0}, row_agg(nf), agg_ref;
+            for (uint32_t f0 = 0; f0 < nf; f0 += per) {
+                const uint32_t f1 = std::min(nf, f0 + per);
+                for (uint32_t f = f0; f < f1; f++) row_agg[f] = (uint32_t)agg_ref.size();
+                agg_ref.push_back(free_cam[f0]);
+                agg_ptr.push_back(f1);
+            }
+            h->tl_n_agg = (uint32_t)agg_ref.size();
+            h->tl_ncp = (h->tl_n_agg * 6 + 59) / 60 * 60;
+            std::vector<uint32_t> cb_ptr, cb_ent, cb_I, cb_J;
+            two_level_lists(h->tl_n_agg, row_agg.data(), h->n_blocks, h->h_blk_row.data(), h->h_blk_col.data(), cb_ptr, cb_ent, cb_I, cb_J);
+            h->tl_n_cb = (uint32_t)cb_I.size();
+            SOSLAM_CHECK(h->tl_agg_ptr.upload(agg_ptr, s));
+            SOSLAM_CHECK(h->tl_row_agg.upload(row_agg, s));
+            SOSLAM_CHECK(h->tl_agg_ref.upload(agg_ref, s));
+            SOSLAM_CHECK(h->tl_cb_ptr.upload(cb_ptr, s));
+            SOSLAM_CHECK(h->tl_cb_ent.upload(cb_ent, s));
+            SOSLAM_CHECK(h->tl_cb_I.upload(cb_I, s));
+            SOSLAM_CHECK(h->tl_cb_J.upload(cb_J, s));
+            SOSLAM_CHECK(h->tl_P.alloc((size_t)nf * 36));
+            SOSLAM_CHECK(h->tl_G.alloc((size_t)h->tl_n_agg * 36));
+            SOSLAM_CHECK(h->tl_Ac0.alloc((size_t)h->tl_ncp * h->tl_ncp));
+            SOSLAM_CHECK(h->tl_Ainv.alloc((size_t)h->tl_ncp * h->tl_ncp));
+            SOSLAM_CHECK(h->tl_ebuf.alloc(2 * 3600));
+            SOSLAM_CHECK(h->tl_rc.alloc(h->tl_ncp));
+            SOSLAM_CHECK(h->tl_rc.zero(s));
+            SOSLAM_CHECK(h->tl_status.alloc(8));
+            SOSLAM_CHECK(h->tl_status.zero(s));
+            SOSLAM_CHECK(h->lin_work.alloc(std::max({pcg_work_count(nf), pcg_band_work_count(nf), pcg_multi_work_count(nf), pcg2_work_count(nf, h->tl_n_agg)})));
+            h->tl_last_it = 0;
+        }
     }
     h->reduce_main = (uint64_t)h->n_blocks * 36 + (uint64_t)nf * 18 + 4;
     h->reduce_count = h->reduce_main + SC_COUNT;
@@ -1025,7 +1074,6 @@ void run_schur(soslam_ba* h, const LmDiag& lm)
                       h->slab.p, h->scalp());
 }
 
-constexpr uint32_t kPcgMultiMinRows = 64;   // below this one workgroup does a whole PCG iteration faster than three launches
 
 // one trust-region step from the current linearisation: reduced system, solve, candidate, candidate cost
 int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vote = false)
@@ -1101,7 +1149,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                     launch_dense_cholesky_solve(s, h->n_free * 6, h->dense.p, h->rhs(), h->dc_free.p, h->scalp());
                 }
             } else if (h->use_cr && h->solver == SOSLAM_SOLVER_BAND_CHOLESKY) {
-                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp, nullptr, h->rhs());
+                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws.p, h->scalp(), &damp, h->rhs());
                 launch_cr_solve(s, h->n_free, h->bw, h->cr_ws.p, h->rhs(), h->dc_free.p, nullptr, true);
             } else if (h->use_cr && h->pcg_band) {
                 // LAGGED FACTOR.  Once the iterates have all but converged (the last accepted step lowered the cost by less than
@@ -1123,7 +1171,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                     SOSLAM_CHECK(h->lag_init());
                     SOSLAM_HIP_CHECK(hipEventRecord(h->ev_s_ready, s));
                     SOSLAM_HIP_CHECK(hipStreamWaitEvent(h->fstream, h->ev_s_ready, 0));
-                    launch_cr_factor(h->fstream, bsr_view(h), h->cr_map.p, h->bw, ws_new, h->lag_status.p, nullptr, nullptr, nullptr);
+                    launch_cr_factor(h->fstream, bsr_view(h), h->cr_map.p, h->bw, ws_new, h->lag_status.p, nullptr, nullptr);
                     SOSLAM_HIP_CHECK(hipEventRecord(h->ev_factor, h->fstream));
                     h->fac_pending = true;
                     launch_pcg_cr(s, bsr_view(h), h->bw, ws_old, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p, h->opt.pcg_tolerance,
@@ -1132,7 +1180,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                 } else {
                 h->lagged_solve = false;
                 if (!h->off_band) {
-                    launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws_of(h->fac_idx), h->scalp(), &damp, nullptr, h->rhs());
+                    launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws_of(h->fac_idx), h->scalp(), &damp, h->rhs());
                 } else {
                     // The factored band leaves blocks of S out, and the band part of a positive definite matrix need not be
                     // positive definite.  A breakdown must not become an invalid LM step (the reference's direct solver has
@@ -1141,7 +1189,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                     // following iterations; at share 1 the factored matrix is positive definite whatever was left out).
                     launch_cr_comp(s, h->S(), h->n_free, h->cr_comp_ptr.p, h->cr_comp_ent.p, h->cr_comp.p);
                     for (int attempt = 0; attempt < 6; attempt++) {
-                        launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws_of(h->fac_idx), h->scalp(), attempt == 0 ? &damp : nullptr, nullptr,
+                        launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->bw, h->cr_ws_of(h->fac_idx), h->scalp(), attempt == 0 ? &damp : nullptr,
                                          h->rhs(), h->cr_comp.p, h->comp_share);
                         double st = 0.0;
                         SOSLAM_HIP_CHECK(hipMemcpyAsync(&st, h->scalp() + SC_LIN_STATUS, sizeof st, hipMemcpyDeviceToHost, s));
@@ -1183,10 +1231,22 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                                 h->scalp());
                 resid = h->lin_resid.p;
             } else if (h->n_free >= kPcgMultiMinRows) {
-                // no band to factor: block-Jacobi PCG with every vector operation spread over many workgroups
+                // no band to factor: PCG with every vector operation spread over many workgroups - block-Jacobi plus, when set up
+                // (build_problem), the rigid-body coarse space
                 double rel = 0.0;
-                const int it = pcg_multi_solve(s, bsr_view(h), 0.0, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
-                                               h->opt.pcg_tolerance, h->opt.pcg_max_iterations, 16, &rel);
+                int it;
+                if (h->two_level) {
+                    launch_ba_coarse_basis(s, h->n_free, h->free_cam.p, h->tl_row_agg.p, h->tl_agg_ref.p, h->campre.p, h->tl_P.p);
+                    launch_coarse_assemble(s, h->tl_n_agg, h->tl_agg_ptr.p, h->tl_n_cb, h->tl_cb_ptr.p, h->tl_cb_ent.p, h->tl_cb_I.p, h->tl_cb_J.p,
+                                           h->blk_row.p, h->blk_col.p, h->S(), h->tl_P.p, h->tl_ncp, h->tl_G.p, h->tl_Ac0.p);
+                    pcg2_coarse_inverse(s, h->tl_n_agg, h->tl_ncp, h->tl_Ac0.p, h->tl_G.p, 0.0, h->tl_Ainv.p, h->tl_ebuf.p, h->tl_status.p);
+                    const TwoLevelView tl{h->tl_n_agg, h->tl_ncp, h->tl_agg_ptr.p, h->tl_P.p, h->tl_Ainv.p, h->tl_rc.p};
+                    it = pcg2_solve(s, bsr_view(h), 0.0, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p, tl, h->opt.pcg_tolerance,
+                                    h->opt.pcg_max_iterations, h->tl_last_it > 0 ? h->tl_last_it + 2 : 48, &rel);
+                    if (it > 0) h->tl_last_it = it;
+                } else
+                it = pcg_multi_solve(s, bsr_view(h), 0.0, h->rhs(), h->dc_free.p, h->lin_resid.p, h->lin_work.p,
+                                     h->opt.pcg_tolerance, h->opt.pcg_max_iterations, 16, &rel);
                 const double lin[3] = {(double)std::max(it, 0), rel, it < 0 ? 2.0 : 0.0};   // SC_LIN_ITERS, _RESID, _STATUS
                 static_assert(SC_LIN_RESID == SC_LIN_ITERS + 1 && SC_LIN_STATUS == SC_LIN_ITERS + 2, "scalar slots are contiguous");
                 SOSLAM_HIP_CHECK(hipMemcpyAsync(h->scalp() + SC_LIN_ITERS, lin, sizeof lin, hipMemcpyHostToDevice, s));

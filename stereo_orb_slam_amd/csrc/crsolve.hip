@@ -69,7 +69,7 @@ struct CrView {
 // (cr_build_map): every element of both arrays is written - a 6x6 block of S, its transpose, zero, or the unit
 // diagonal of a padding camera - so no memset precedes it.  blockIdx = (super-block, 0: D / 1: F).
 __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blocks, const int32_t* __restrict__ map, const CrView v,
-                                                        const CamDamp damp, const CrShift shift, const double* __restrict__ comp, const double comp_scale)
+                                                        const CamDamp damp, const double* __restrict__ comp, const double comp_scale)
 {
     const int sb = v.sb, bw = v.bw;
     const uint32_t i = blockIdx.x;
@@ -98,13 +98,7 @@ __global__ __launch_bounds__(256) void cr_gather_kernel(double* __restrict__ blo
     // lane = column, wave = every fourth row: divisions by the constant 6 only, coalesced stores, independent loads
     const int c = threadIdx.x % 64, lb = c / 6, cc = c - lb * 6;
     if (c >= sb) return;
-    // a factor made for ANOTHER damping than the one S carries (lagged preconditioner, see CrShift): the difference goes
-    // onto D's diagonal, S itself is left alone
     double extra = 0.0;
-    if (shift.diagB && !is_f) {
-        const uint32_t u = i * (uint32_t)sb + (uint32_t)c;
-        if (u < shift.n_free * 6) extra = point_lambda(shift.diagB[u], shift.sc[u], shift.lm) - shift.lc[u];
-    }
     // blocks of S outside the block-tridiagonal part are not factored (off-band mode).  The band part of a positive definite
     // matrix need not be positive definite; a share comp_scale of the left-out blocks' absolute row sums on the diagonal makes
     // it so (at comp_scale = 1 the factored matrix exceeds S by a diagonally dominant one) - the caller raises the share only
@@ -1347,14 +1341,13 @@ void cr_build_comp_lists(uint32_t n_rows, int bw, uint32_t n_blocks, const uint3
 }
 
 void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp,
-                      const CrShift* shift, const double* fwd_b, const double* comp, double comp_scale)
+                      const double* fwd_b, const double* comp, double comp_scale)
 {
     if (!A.n_rows) return;
     const CrView v = make_view(A.n_rows, bw, ws);
     CamDamp none{};
-    CrShift no_shift{};
     hipLaunchKernelGGL(cr_gather_kernel, dim3(v.m, 2), dim3(256), 0, s, const_cast<double*>(A.blocks), map, v, damp ? *damp : none,
-                       shift ? *shift : no_shift, comp_scale > 0.0 ? comp : nullptr, comp_scale);
+                       comp_scale > 0.0 ? comp : nullptr, comp_scale);
     const size_t lds_r = sizeof(double) * 4 * kImgRows * kLd;
     if (lds_r > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cr_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
     const uint32_t nt = ((uint32_t)v.sb + 15) / 16;

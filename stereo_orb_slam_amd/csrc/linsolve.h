@@ -100,13 +100,12 @@ size_t cr_map_count(uint32_t n_rows, int bw);   // int32 entries of the gather m
 void cr_build_map(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, int32_t* map);   // host
 // damp != NULL: the gather also applies the camera damping to S in place (instead of a launch_cam_damp before it)
 struct CamDamp;
-struct CrShift;   // ba_kernels.h: the factor is made for another damping than the one S carries
 // fwd_b != NULL: the factorisation also carries the forward sweep of the solve that follows for this right-hand side (the
 // levels launch_cr_solve would run as pairs); that solve must then be called with forward_done = true and the same b
 // comp != NULL and comp_scale > 0 (off-band mode: some blocks of A lie outside the factored band): comp_scale * comp is added to
 // the diagonal of the factored matrix
 void launch_cr_factor(hipStream_t s, const BsrView& A, const int32_t* map, int bw, double* ws, double* scal, const CamDamp* damp,
-                      const CrShift* shift = nullptr, const double* fwd_b = nullptr, const double* comp = nullptr, double comp_scale = 0.0);
+                      const double* fwd_b = nullptr, const double* comp = nullptr, double comp_scale = 0.0);
 // off-band mode: comp = absolute row sums of the blocks the map leaves out (lists from cr_build_comp_lists)
 void cr_build_comp_lists(uint32_t n_rows, int bw, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, std::vector<uint32_t>& ptr,
                          std::vector<uint32_t>& ent);
@@ -150,6 +149,12 @@ struct TwoLevelView {
     double* rc;                  // [ncp] P^T r (entries from 6 n_agg on stay zero)
 };
 size_t pcg2_work_count(uint32_t n_rows, uint32_t n_agg);
+// set-up of the coarse space: lists (host, once per pattern) and G = P^T P, Ac0 = P^T A P (device, once per matrix)
+void two_level_lists(uint32_t n_agg, const uint32_t* row_agg, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
+                     std::vector<uint32_t>& cb_ptr, std::vector<uint32_t>& cb_ent, std::vector<uint32_t>& cb_I, std::vector<uint32_t>& cb_J);
+void launch_coarse_assemble(hipStream_t s, uint32_t n_agg, const uint32_t* agg_ptr, uint32_t n_cb, const uint32_t* cb_ptr, const uint32_t* cb_ent,
+                            const uint32_t* cb_I, const uint32_t* cb_J, const uint32_t* blk_row, const uint32_t* blk_col, const double* blocks,
+                            const double* P, uint32_t ncp, double* G, double* Ac0);
 // the coarse operator (P^T A P + shift P^T P)^-1 into ainv_out: Ac0 = P^T A P ([ncp * ncp], without the shift), G = P^T P per
 // aggregate ([n_agg][36]), ebuf 2 x 3600 f64 of scratch, status[0] = 1 on a non-positive pivot tile.  Any symmetric positive
 // definite coarse operator makes a valid preconditioner: the caller may hand pcg2_solve the inverse of an EARLIER matrix.

@@ -454,6 +454,73 @@ __global__ __launch_bounds__(kThreads) void pcg2_update_kernel(double* __restric
     }
 }
 
+// G_I = sum over the aggregate's block rows of P_v^T P_v (the shift's share of the coarse matrix); one wave per aggregate
+__global__ __launch_bounds__(64) void coarse_gram_kernel(const uint32_t* __restrict__ agg_ptr, const double* __restrict__ P, double* __restrict__ G)
+{
+    const uint32_t I = blockIdx.x;
+    const int e = threadIdx.x;
+    if (e >= 36) return;
+    const int a = e / 6, b = e % 6;
+    double s = 0.0;
+    for (uint32_t f = agg_ptr[I]; f < agg_ptr[I + 1]; f++) {
+        const double* Pv = P + 36 * (size_t)f;
+#pragma unroll
+        for (int c = 0; c < 6; c++) s += Pv[c * 6 + a] * Pv[c * 6 + b];
+    }
+    G[36 * (size_t)I + e] = s;
+}
+
+// one coarse block (I, J) of P^T H P: the sum over its fine blocks (entry = 2 * block + swap; swap: the stored block is H(i, j)
+// with i in J and j in I, so its transpose is what couples I to J).  One workgroup per coarse block: seven groups of 36 lanes take
+// every seventh fine block of the list, their partial sums are added in group order (fixed order: reproducible).
+constexpr int kAsmGroups = 7;
+__global__ __launch_bounds__(256) void coarse_assemble_kernel(const uint32_t* __restrict__ cb_ptr, const uint32_t* __restrict__ cb_ent,
+                                                                 const uint32_t* __restrict__ cb_I, const uint32_t* __restrict__ cb_J,
+                                                                 const uint32_t* __restrict__ blk_row, const uint32_t* __restrict__ blk_col,
+                                                                 const double* __restrict__ H, const double* __restrict__ P, const uint32_t ncp,
+                                                                 double* __restrict__ Ac0)
+{
+    __shared__ double T[kAsmGroups][36];
+    __shared__ double part[kAsmGroups][36];
+    const uint32_t cb = blockIdx.x;
+    const int grp = threadIdx.x / 36, e = threadIdx.x % 36, a = e / 6, b = e % 6;
+    const bool on = grp < kAsmGroups;
+    double acc = 0.0;
+    const uint32_t q0 = cb_ptr[cb], q1 = cb_ptr[cb + 1];
+    // uniform trip count: every lane reaches the barriers
+    for (uint32_t base = q0; base < q1; base += kAsmGroups) {
+        const uint32_t q = base + (uint32_t)grp;
+        const bool live = on && q < q1;
+        const double* L = nullptr;
+        if (live) {
+            const uint32_t blk = cb_ent[q] >> 1, swap = cb_ent[q] & 1;
+            const uint32_t i = blk_row[blk], j = blk_col[blk];
+            const double* Hb = H + 36 * (size_t)blk;
+            L = P + 36 * (size_t)(swap ? j : i);
+            const double* Rr = P + 36 * (size_t)(swap ? i : j);
+            double t = 0.0;   // T = Hm Rr with Hm = Hb or Hb^T
+#pragma unroll
+            for (int d = 0; d < 6; d++) t += (swap ? Hb[d * 6 + a] : Hb[a * 6 + d]) * Rr[d * 6 + b];
+            T[grp][e] = t;
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc += L[c * 6 + a] * T[grp][c * 6 + b];
+        }
+        __syncthreads();
+    }
+    if (on) part[grp][e] = acc;
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        double sum = 0.0;
+#pragma unroll
+        for (int g = 0; g < kAsmGroups; g++) sum += part[g][threadIdx.x];
+        Ac0[(size_t)(6 * cb_I[cb] + a) * ncp + 6 * cb_J[cb] + b] = sum;
+    }
+}
+
+
 // Ainv <- Ac0 + shift * blockdiag(G) on the coarse unknowns, the identity on the padding; the caller inverts it in place
 __global__ __launch_bounds__(256) void pcg2_coarse_matrix_kernel(const double* __restrict__ Ac0, const double* __restrict__ G, const double shift,
                                                                  const uint32_t nc, const uint32_t ncp, double* __restrict__ out)
@@ -597,6 +664,42 @@ int pcg2_solve(hipStream_t s, const BsrView& A, double shift, const double* b, d
     }
     if (rel_resid) *rel_resid = host_state[ST_BB] > 0 ? std::sqrt(rr / host_state[ST_BB]) : 0.0;
     return (int)host_state[ST_ITERS];
+}
+
+// G = P^T P per aggregate and Ac0 = P^T A P (dense, leading dimension ncp) from the block rows' coarse bases P and the blocks of A
+void launch_coarse_assemble(hipStream_t s, uint32_t n_agg, const uint32_t* agg_ptr, uint32_t n_cb, const uint32_t* cb_ptr, const uint32_t* cb_ent,
+                            const uint32_t* cb_I, const uint32_t* cb_J, const uint32_t* blk_row, const uint32_t* blk_col, const double* blocks,
+                            const double* P, uint32_t ncp, double* G, double* Ac0)
+{
+    if (!n_agg) return;
+    hipLaunchKernelGGL(coarse_gram_kernel, dim3(n_agg), dim3(64), 0, s, agg_ptr, P, G);
+    (void)hipMemsetAsync(Ac0, 0, sizeof(double) * (size_t)ncp * ncp, s);
+    if (n_cb) hipLaunchKernelGGL(coarse_assemble_kernel, dim3(n_cb), dim3(256), 0, s, cb_ptr, cb_ent, cb_I, cb_J, blk_row, blk_col, blocks, P, ncp, Ac0);
+}
+
+// host: the non-empty coarse blocks (ordered aggregate pairs) of a block-sparse matrix (upper blocks blk_row <= blk_col) and the
+// fine blocks that feed them, in block order (entry = 2 * block + swap)
+void two_level_lists(uint32_t n_agg, const uint32_t* row_agg, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col,
+                     std::vector<uint32_t>& cb_ptr, std::vector<uint32_t>& cb_ent, std::vector<uint32_t>& cb_I, std::vector<uint32_t>& cb_J)
+{
+    std::vector<std::pair<uint64_t, uint32_t>> items;
+    items.reserve((size_t)n_blocks * 2);
+    for (uint32_t blk = 0; blk < n_blocks; blk++) {
+        const uint64_t I = row_agg[blk_row[blk]], J = row_agg[blk_col[blk]];
+        items.push_back({I * n_agg + J, 2 * blk});
+        if (blk_row[blk] != blk_col[blk]) items.push_back({J * n_agg + I, 2 * blk + 1});
+    }
+    std::sort(items.begin(), items.end());
+    cb_ptr.clear(); cb_ent.clear(); cb_I.clear(); cb_J.clear();
+    for (size_t q = 0; q < items.size(); q++) {
+        if (q == 0 || items[q].first != items[q - 1].first) {
+            cb_ptr.push_back((uint32_t)q);
+            cb_I.push_back((uint32_t)(items[q].first / n_agg));
+            cb_J.push_back((uint32_t)(items[q].first % n_agg));
+        }
+        cb_ent.push_back(items[q].second);
+    }
+    cb_ptr.push_back((uint32_t)items.size());
 }
 
 }  // namespace soslam

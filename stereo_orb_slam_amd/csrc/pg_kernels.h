@@ -32,11 +32,8 @@ void launch_pg_reduce(hipStream_t s, const double* part, uint32_t n, const doubl
 void launch_pg_update(hipStream_t s, uint32_t n_vertex, const double* est, const int32_t* free_idx, const double* x,
                       const double* b, double lambda, double* cand, double* scale_part);
 
-// two-level preconditioner: P (per free vertex), G = P^T P per aggregate, Ac0 = P^T H P (dense, leading dimension ncp) at the
-// current estimates and H; lists built by pg_solver.hip::build_graph
-void launch_pg_coarse_setup(hipStream_t s, uint32_t n_free, uint32_t n_agg, const uint32_t* free_vertex, const uint32_t* row_agg,
-                            const uint32_t* agg_ref, const uint32_t* agg_ptr, const double* est, uint32_t n_cb, const uint32_t* cb_ptr,
-                            const uint32_t* cb_ent, const uint32_t* cb_I, const uint32_t* cb_J, const uint32_t* blk_row, const uint32_t* blk_col,
-                            const double* H, uint32_t ncp, double* P, double* G, double* Ac0);
+// two-level preconditioner (pcg_multi.hip): the coarse basis P of the free vertices at the current estimates
+void launch_pg_coarse_basis(hipStream_t s, uint32_t n_free, const uint32_t* free_vertex, const uint32_t* row_agg, const uint32_t* agg_ref,
+                            const double* est, double* P);
 
 }  // namespace soslam

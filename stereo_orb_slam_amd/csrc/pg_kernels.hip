@@ -358,72 +358,6 @@ __global__ __launch_bounds__(256) void pg_coarse_basis_kernel(const uint32_t n_f
         }
 }
 
-// G_I = sum over the aggregate's vertices of P_v^T P_v (the shift's share of the coarse matrix); one wave per aggregate
-__global__ __launch_bounds__(64) void pg_coarse_gram_kernel(const uint32_t* __restrict__ agg_ptr, const double* __restrict__ P, double* __restrict__ G)
-{
-    const uint32_t I = blockIdx.x;
-    const int e = threadIdx.x;
-    if (e >= 36) return;
-    const int a = e / 6, b = e % 6;
-    double s = 0.0;
-    for (uint32_t f = agg_ptr[I]; f < agg_ptr[I + 1]; f++) {
-        const double* Pv = P + 36 * (size_t)f;
-#pragma unroll
-        for (int c = 0; c < 6; c++) s += Pv[c * 6 + a] * Pv[c * 6 + b];
-    }
-    G[36 * (size_t)I + e] = s;
-}
-
-// one coarse block (I, J) of P^T H P: the sum over its fine blocks (entry = 2 * block + swap; swap: the stored block is H(i, j)
-// with i in J and j in I, so its transpose is what couples I to J).  One workgroup per coarse block: seven groups of 36 lanes take
-// every seventh fine block of the list, their partial sums are added in group order (fixed order: reproducible).
-constexpr int kAsmGroups = 7;
-__global__ __launch_bounds__(256) void pg_coarse_assemble_kernel(const uint32_t* __restrict__ cb_ptr, const uint32_t* __restrict__ cb_ent,
-                                                                 const uint32_t* __restrict__ cb_I, const uint32_t* __restrict__ cb_J,
-                                                                 const uint32_t* __restrict__ blk_row, const uint32_t* __restrict__ blk_col,
-                                                                 const double* __restrict__ H, const double* __restrict__ P, const uint32_t ncp,
-                                                                 double* __restrict__ Ac0)
-{
-    __shared__ double T[kAsmGroups][36];
-    __shared__ double part[kAsmGroups][36];
-    const uint32_t cb = blockIdx.x;
-    const int grp = threadIdx.x / 36, e = threadIdx.x % 36, a = e / 6, b = e % 6;
-    const bool on = grp < kAsmGroups;
-    double acc = 0.0;
-    const uint32_t q0 = cb_ptr[cb], q1 = cb_ptr[cb + 1];
-    // uniform trip count: every lane reaches the barriers
-    for (uint32_t base = q0; base < q1; base += kAsmGroups) {
-        const uint32_t q = base + (uint32_t)grp;
-        const bool live = on && q < q1;
-        const double* L = nullptr;
-        if (live) {
-            const uint32_t blk = cb_ent[q] >> 1, swap = cb_ent[q] & 1;
-            const uint32_t i = blk_row[blk], j = blk_col[blk];
-            const double* Hb = H + 36 * (size_t)blk;
-            L = P + 36 * (size_t)(swap ? j : i);
-            const double* Rr = P + 36 * (size_t)(swap ? i : j);
-            double t = 0.0;   // T = Hm Rr with Hm = Hb or Hb^T
-#pragma unroll
-            for (int d = 0; d < 6; d++) t += (swap ? Hb[d * 6 + a] : Hb[a * 6 + d]) * Rr[d * 6 + b];
-            T[grp][e] = t;
-        }
-        __syncthreads();
-        if (live) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) acc += L[c * 6 + a] * T[grp][c * 6 + b];
-        }
-        __syncthreads();
-    }
-    if (on) part[grp][e] = acc;
-    __syncthreads();
-    if (threadIdx.x < 36) {
-        double sum = 0.0;
-#pragma unroll
-        for (int g = 0; g < kAsmGroups; g++) sum += part[g][threadIdx.x];
-        Ac0[(size_t)(6 * cb_I[cb] + a) * ncp + 6 * cb_J[cb] + b] = sum;
-    }
-}
-
 }  // namespace
 
 void launch_pg_linearize(hipStream_t s, uint32_t n_edge, const double* est, const uint32_t* ef, const uint32_t* et,
@@ -463,16 +397,11 @@ void launch_pg_update(hipStream_t s, uint32_t n_vertex, const double* est, const
                        scale_part);
 }
 
-void launch_pg_coarse_setup(hipStream_t s, uint32_t n_free, uint32_t n_agg, const uint32_t* free_vertex, const uint32_t* row_agg,
-                            const uint32_t* agg_ref, const uint32_t* agg_ptr, const double* est, uint32_t n_cb, const uint32_t* cb_ptr,
-                            const uint32_t* cb_ent, const uint32_t* cb_I, const uint32_t* cb_J, const uint32_t* blk_row, const uint32_t* blk_col,
-                            const double* H, uint32_t ncp, double* P, double* G, double* Ac0)
+void launch_pg_coarse_basis(hipStream_t s, uint32_t n_free, const uint32_t* free_vertex, const uint32_t* row_agg, const uint32_t* agg_ref,
+                            const double* est, double* P)
 {
-    if (!n_free || !n_agg) return;
+    if (!n_free) return;
     hipLaunchKernelGGL(pg_coarse_basis_kernel, dim3((n_free + 255) / 256), dim3(256), 0, s, n_free, free_vertex, row_agg, agg_ref, est, P);
-    hipLaunchKernelGGL(pg_coarse_gram_kernel, dim3(n_agg), dim3(64), 0, s, agg_ptr, P, G);
-    (void)hipMemsetAsync(Ac0, 0, sizeof(double) * (size_t)ncp * ncp, s);
-    if (n_cb) hipLaunchKernelGGL(pg_coarse_assemble_kernel, dim3(n_cb), dim3(256), 0, s, cb_ptr, cb_ent, cb_I, cb_J, blk_row, blk_col, H, P, ncp, Ac0);
 }
 
 }  // namespace soslam

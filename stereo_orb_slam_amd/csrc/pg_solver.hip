@@ -195,24 +195,7 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     };
     std::vector<uint32_t> cb_ptr, cb_ent, cb_I, cb_J;
     if (h->two_level) {
-        // non-empty coarse blocks (ordered aggregate pairs) and the fine blocks that feed them, in block order
-        std::vector<std::pair<uint64_t, uint32_t>> items;   // (I * n_agg + J, 2 * block + swap)
-        items.reserve((size_t)h->n_blocks * 2);
-        for (uint32_t blk = 0; blk < h->n_blocks; blk++) {
-            const uint64_t I = row_agg[h->h_blk_row[blk]], J = row_agg[h->h_blk_col[blk]];
-            items.push_back({I * h->n_agg + J, 2 * blk});
-            if (h->h_blk_row[blk] != h->h_blk_col[blk]) items.push_back({J * h->n_agg + I, 2 * blk + 1});
-        }
-        std::sort(items.begin(), items.end());
-        for (size_t q = 0; q < items.size(); q++) {
-            if (q == 0 || items[q].first != items[q - 1].first) {
-                cb_ptr.push_back((uint32_t)q);
-                cb_I.push_back((uint32_t)(items[q].first / h->n_agg));
-                cb_J.push_back((uint32_t)(items[q].first % h->n_agg));
-            }
-            cb_ent.push_back(items[q].second);
-        }
-        cb_ptr.push_back((uint32_t)items.size());
+        two_level_lists(h->n_agg, row_agg.data(), h->n_blocks, h->h_blk_row.data(), h->h_blk_col.data(), cb_ptr, cb_ent, cb_I, cb_J);
         h->n_cb = (uint32_t)cb_I.size();
     }
     std::vector<PgEdgeBlocks> eb(n_edge);
@@ -346,9 +329,11 @@ int linearize(soslam_pg* h, double* dbg_e, double* dbg_ji, double* dbg_jj)
         h->cinv_pending = false;
         h->cinv_cur ^= 1;
     }
-    if (h->two_level)
-        launch_pg_coarse_setup(s, h->n_free, h->n_agg, h->free_vertex.p, h->row_agg.p, h->agg_ref.p, h->agg_ptr.p, h->est[h->cur].p, h->n_cb,
-                               h->cb_ptr.p, h->cb_ent.p, h->cb_I.p, h->cb_J.p, h->blk_row.p, h->blk_col.p, h->H.p, h->ncp, h->cP.p, h->cG.p, h->cAc0.p);
+    if (h->two_level) {
+        launch_pg_coarse_basis(s, h->n_free, h->free_vertex.p, h->row_agg.p, h->agg_ref.p, h->est[h->cur].p, h->cP.p);
+        launch_coarse_assemble(s, h->n_agg, h->agg_ptr.p, h->n_cb, h->cb_ptr.p, h->cb_ent.p, h->cb_I.p, h->cb_J.p, h->blk_row.p, h->blk_col.p,
+                               h->H.p, h->cP.p, h->ncp, h->cG.p, h->cAc0.p);
+    }
     SOSLAM_HIP_CHECK(hipGetLastError());
     return SOSLAM_OK;
 }

@@ -578,7 +578,8 @@ def test_tracks_longer_than_the_window(gpu, oracle_lib, solver):
 
 def test_wide_band_uses_multi_workgroup_pcg(gpu, oracle_lib):
     """Tracks of 24 cameras over a 150-camera chain: block half-bandwidth 23 is beyond both band factorisations, so
-    PCG runs block-Jacobi preconditioned with every vector operation spread over many workgroups (pcg_multi.hip)."""
+    PCG runs with every vector operation spread over many workgroups (pcg_multi.hip) - block-Jacobi plus, since round 3, the
+    rigid-body coarse space (pcg2_solve)."""
     ba, synth, L = gpu
     p = synth.generate_ba(None, n_cam=150, n_pt=6000, track_mode=0, track_len=24, spacing=0.3)
     ref = oracle_lib.step(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, 1e4)
@@ -590,6 +591,46 @@ def test_wide_band_uses_multi_workgroup_pcg(gpu, oracle_lib):
     np.testing.assert_allclose(dc, ref["dc"], rtol=1e-5, atol=1e-8 * np.abs(ref["dc"]).max())
     np.testing.assert_allclose(dp, ref["dp"], rtol=1e-5, atol=1e-8 * np.abs(ref["dp"]).max())
     assert sc[1] == pytest.approx(ref["model_cost_change"], rel=1e-7)
+
+
+def _merge_problems(synth, p, q):
+    oc = np.concatenate([p.obs_cam, q.obs_cam]); op = np.concatenate([p.obs_pt, q.obs_pt + np.uint32(p.n_pt)])
+    uv = np.concatenate([p.obs_uv, q.obs_uv]); order = np.lexsort((op, oc))
+    return synth.BaProblem(p.poses_wc, np.concatenate([p.points, q.points]), oc[order], op[order], uv[order], p.proj_l, p.proj_r)
+
+
+def test_two_level_pcg_on_a_band_wider_than_the_factors(gpu, oracle_lib):
+    """Tracks longer than ten cameras on a long chain (200 cameras; 90 % of the points seen by 10 consecutive cameras, 10 % by 20):
+    block half-bandwidth 19, beyond both band factorisations.  Round 2 ran block-Jacobi PCG there (hundreds of iterations per
+    solve: the chain's drift modes); now six rigid-body modes per aggregate of 12 consecutive cameras form a coarse space
+    (pcg2_solve, the pose graph's two-level PCG).  The iterates must be the oracle's (its solver is direct) and the PCG must take
+    a fraction of block-Jacobi's iterations."""
+    ba, synth, L = gpu
+    p = _merge_problems(synth, synth.generate_ba(None, n_cam=200, n_pt=40000, track_mode=0, track_len=10),
+                        synth.generate_ba(None, n_cam=200, n_pt=4000, track_mode=0, track_len=20))
+    iters = 8
+    runs = {}
+    for name, env in (("two_level", None), ("block_jacobi", "1")):
+        if env:
+            os.environ["SOSLAM_NO_TWO_LEVEL"] = env
+        else:
+            os.environ.pop("SOSLAM_NO_TWO_LEVEL", None)
+        try:
+            with ba.BundleAdjustment(ba.default_options(linear_solver=2, pcg_tolerance=1e-10, pcg_max_iterations=4000)) as h:
+                h.load(p)
+                h.iterate(iters)
+                runs[name] = (h.iteration_log(), h.get_state()[0])
+        finally:
+            os.environ.pop("SOSLAM_NO_TWO_LEVEL", None)
+    o = oracle_lib.default_options(max_iterations=iters, check_termination=0, num_threads=min(16, os.cpu_count() or 1))
+    ocams, _, osum, olog = oracle_lib.solve(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, o)
+    log, cams = runs["two_level"]
+    assert [it.accepted for it in log] == [e.accepted for e in olog]
+    np.testing.assert_allclose([it.cost for it in log], [e.cost for e in olog], rtol=1e-7)
+    assert np.abs(cams - ocams).max() < ABS_POSE
+    two = sum(it.linear_iterations for it in log[1:])
+    bj = sum(it.linear_iterations for it in runs["block_jacobi"][0][1:])
+    assert max(it.linear_iterations for it in log[1:]) <= 150 and two * 3 < bj, (two, bj)
 
 
 def test_a_kept_handle_gives_the_same_answers(gpu, prob1):
