@@ -345,4 +345,29 @@ __device__ __forceinline__ bool sym3_chol_inverse(const double* __restrict__ m, 
     return ok;
 }
 
+struct Publish {   // optional tail of a one-workgroup kernel: n <= 64 doubles to pinned host memory, then a sequence number;
+                   // the slots [clear_first, clear_first + clear_n) of src (status words) are zeroed for the next iteration
+    double* src;
+    double* host_dst;
+    unsigned long long* host_seq;
+    unsigned long long seq;
+    int n, clear_first, clear_n;
+};
+
+__device__ __forceinline__ void publish_tail(const Publish& pb)
+{
+    if (!pb.host_dst) return;   // uniform
+    __syncthreads();            // the kernel's own result is among the published values
+    const int t = threadIdx.x;
+    if (t < pb.n) {
+        pb.host_dst[t] = pb.src[t];
+        if (t >= pb.clear_first && t < pb.clear_first + pb.clear_n) pb.src[t] = 0.0;
+    }
+    // only the first wave has written anything (n <= 64): the other waves of a 1024-lane kernel skip the system-scope
+    // fence, whose cache write-back every wave would otherwise repeat
+    if (t < 64) __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __atomic_store_n(pb.host_seq, pb.seq, __ATOMIC_RELEASE);
+}
+
 }  // namespace soslam

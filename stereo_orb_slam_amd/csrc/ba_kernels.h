@@ -158,6 +158,13 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
 // into +inf before the scalars are summed, so every rank sees a non-finite candidate and rejects the step alike.
 void launch_status_poison(hipStream_t s, double* scal);
 
+// ---- small problems' uploads in one command ------------------------------------------------------------------------------
+// The index of a window of a few thousand observations is ~35 arrays of a few KB: as separate copy commands they cost more than
+// the index takes to build.  The host packs them into one pinned buffer (table of segments, then the 16-byte aligned payloads)
+// and ONE kernel reads that buffer over the link and writes every array where it belongs (src_offset = ~0: fill with zeros).
+struct PackedSeg { void* dst; uint64_t src_offset; uint64_t bytes; };
+void launch_packed_scatter(hipStream_t s, const PackedSeg* table, int n_seg, const unsigned char* payload);
+
 // ---- structure-only problems (every camera constant: BundleAdjuster::Optimize(n-1, n), /root/reference/src/slam.cpp:123) ----
 // The problem decouples into independent 3-variable blocks under ONE trust region.  For problems of at most
 // kPointsOnlyMax points a single workgroup does a whole LM iteration in one launch: linearise every point at x (J_p^T J_p,
@@ -187,6 +194,33 @@ void launch_points_step(hipStream_t s, const PointsStepArgs& a, const Proj& P, d
 // and |dp|_inf into scal[SC_LS_*], published) in one launch
 void launch_points_ls(hipStream_t s, const PointsStepArgs& a, const Proj& P, double step, double* pub_src, int n_pub, double* host_dst,
                       unsigned long long* host_seq, unsigned long long seq);
+
+// The whole structure-only solve in one launch (ba_points.hip): trust-region controller, termination tests and the bounded
+// problem's line search on the device; ceil(n_pt / 64) single-wave workgroups (kPointsOnlyMax / 64 at most: all resident).  In: the controller state of the handle; out (pinned host memory): one record of
+// PSV_COUNT doubles, the iteration log (kPointsLogDoubles doubles per entry, laid out as soslam_ba_iteration), then `seq`.
+enum { PSV_RADIUS = 0, PSV_DECREASE, PSV_X_COST, PSV_CUR, PSV_INVALID_RUN, PSV_ITERATIONS, PSV_ACCEPTED, PSV_TERMINATION, PSV_LS_STEPS,
+       PSV_INITIAL_COST, PSV_N_LOG, PSV_ERROR, PSV_HAVE_INITIAL, PSV_PASSES, PSV_COUNT };
+constexpr int kPointsLogDoubles = 9;
+// termination codes as include/soslam_ba.h numbers them (checked where both are visible: ba_solver.hip)
+enum { kPointsTermMaxIterations = 0, kPointsTermParameter = 1, kPointsTermFunction = 2, kPointsTermGradient = 3, kPointsTermMinRadius = 4,
+       kPointsTermInvalid = 5, kPointsTermTime = 6 };
+struct PointsSolveCtl {
+    double* pts[2];                  // x is pts[cur], the candidate pts[cur ^ 1]
+    int cur, invalid_run, init_scale, x_cost_known;
+    double radius, decrease_factor, x_cost;
+    int max_it, check, constrained;
+    double lm_lo, lm_hi;
+    double min_radius, max_radius, min_relative_decrease, gradient_tolerance, parameter_tolerance, function_tolerance;
+    long long max_ticks;             // wall-clock limit in ticks of the 100 MHz constant clock; 0: none
+    double* log;                     // device scratch, (max_it + 1) entries
+    // the grid barrier / reduction of the single-wave workgroups (one point per lane): records [2][n_wg][16], a counter that only
+    // ever grows (sync_base = its value when this launch starts)
+    int n_wg;
+    double* sync_records; unsigned long long* sync_counter; unsigned long long sync_base;
+    double* host_record; double* host_log;
+    unsigned long long* host_seq; unsigned long long seq;
+};
+void launch_points_solve(hipStream_t s, const PointsStepArgs& a, const Proj& P, const PointsSolveCtl& c);
 
 // ---- Ceres' line search on bounded problems (TrustRegionMinimizer::DoLineSearch; see run_lm) ----------------------------
 // trial point x+ = Plus(x, a delta): cameras x + a dc, points projected onto the box; ls_part[block][2] = {|x+ - x|^2 of the

@@ -282,31 +282,6 @@ struct StepGate {   // the acceptance test of the LM loop for ba_step_sums_kerne
                              // shortens the step when it fails, so the candidate linearised behind the gate would be the wrong one)
 };
 
-struct Publish {   // optional tail of a one-workgroup kernel: n <= 64 doubles to pinned host memory, then a sequence number;
-                   // the slots [clear_first, clear_first + clear_n) of src (status words) are zeroed for the next iteration
-    double* src;
-    double* host_dst;
-    unsigned long long* host_seq;
-    unsigned long long seq;
-    int n, clear_first, clear_n;
-};
-
-__device__ __forceinline__ void publish_tail(const Publish& pb)
-{
-    if (!pb.host_dst) return;   // uniform
-    __syncthreads();            // the kernel's own result is among the published values
-    const int t = threadIdx.x;
-    if (t < pb.n) {
-        pb.host_dst[t] = pb.src[t];
-        if (t >= pb.clear_first && t < pb.clear_first + pb.clear_n) pb.src[t] = 0.0;
-    }
-    // only the first wave has written anything (n <= 64): the other waves of a 1024-lane kernel skip the system-scope
-    // fence, whose cache write-back every wave would otherwise repeat
-    if (t < 64) __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __atomic_store_n(pb.host_seq, pb.seq, __ATOMIC_RELEASE);
-}
-
 __global__ __launch_bounds__(1024) void sum_strided_kernel(const double* __restrict__ in, uint32_t n, uint32_t stride,
                                                             uint32_t offset, double scale, double* __restrict__ out, const Publish pb)
 {
@@ -1393,10 +1368,32 @@ __global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, 
         const uint32_t fa = blk_row[id], fb = blk_col[id];
         const int r = t / 6, c = t % 6;
         if (fa == fb) cam_block_from_tiles(free_cam[fa], cam_tile_start, tile_part, campre, bt, gt, Tm, Bc, gc6);   // block-uniform
-        if (t < 36) {
+        {
+            // the contributions in list order; their offsets arrive 64 at a time, one per lane, and reach the adding lanes as lane
+            // reads - the slab loads of a group are independent of each other and of any index load (a small window's block
+            // collects one contribution per chunk: ~200 at the reference's 20-frame windows)
             double s = 0.0;
-            for (uint32_t e = blk_ptr[id]; e < blk_ptr[id + 1]; e++) s += slab[blk_off[e] + t];
-            t0[t] = s;
+            const uint32_t e1 = blk_ptr[id + 1];
+            for (uint32_t e0 = blk_ptr[id]; e0 < e1; e0 += 64) {
+                const uint32_t n = min(64u, e1 - e0);
+                const uint32_t off = (uint32_t)t < n ? blk_off[e0 + t] : 0u;
+                uint32_t j = 0;
+                for (; j + 8 <= n; j += 8) {   // eight loads in flight, added in list order
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(j + u));
+                        v[u] = t < 36 ? slab[o + t] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) s += v[u];
+                }
+                for (; j < n; j++) {
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)j);
+                    if (t < 36) s += slab[o + t];
+                }
+            }
+            if (t < 36) t0[t] = s;
         }
         __syncthreads();
         if (t < 36) {
@@ -1424,10 +1421,29 @@ __global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, 
         const uint32_t f = id - n_blocks;
         if (f >= n_free) return;
         cam_block_from_tiles(free_cam[f], cam_tile_start, tile_part, campre, bt, gt, Tm, Bc, gc6);
-        if (t < 6) {
+        {
             double s = 0.0;
-            for (uint32_t e = cam_ptr[f]; e < cam_ptr[f + 1]; e++) s += slab[cam_off[e] + t];
-            t0[t] = s;
+            const uint32_t e1 = cam_ptr[f + 1];
+            for (uint32_t e0 = cam_ptr[f]; e0 < e1; e0 += 64) {
+                const uint32_t n = min(64u, e1 - e0);
+                const uint32_t off = (uint32_t)t < n ? cam_off[e0 + t] : 0u;
+                uint32_t j = 0;
+                for (; j + 8 <= n; j += 8) {   // eight loads in flight, added in list order
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(j + u));
+                        v[u] = t < 6 ? slab[o + t] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) s += v[u];
+                }
+                for (; j < n; j++) {
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)j);
+                    if (t < 6) s += slab[o + t];
+                }
+            }
+            if (t < 6) t0[t] = s;
         }
         __syncthreads();
         if (t < 6) {
@@ -1707,6 +1723,27 @@ void launch_sum_strided(hipStream_t s, const double* in, uint32_t n, uint32_t st
     hipLaunchKernelGGL(sum_strided_kernel, dim3(1), dim3(1024), 0, s, in, n, stride, offset, scale, out, Publish{nullptr, nullptr, nullptr, 0ull, 0, 0, 0});
 }
 
+// see PackedSeg: block (i, j) moves slice j of segment i in 16-byte units, slice 0 the odd bytes at the end
+constexpr int kPackSlices = 8;
+__global__ __launch_bounds__(256) void packed_scatter_kernel(const PackedSeg* __restrict__ table, const unsigned char* __restrict__ payload)
+{
+    const PackedSeg sg = table[blockIdx.x];
+    const bool fill = sg.src_offset == ~0ull;
+    const uint4* src = reinterpret_cast<const uint4*>(payload + (fill ? 0 : sg.src_offset));
+    uint4* dst = reinterpret_cast<uint4*>(sg.dst);
+    const uint64_t units = sg.bytes / 16;
+    for (uint64_t u = blockIdx.y * 256u + threadIdx.x; u < units; u += kPackSlices * 256u) dst[u] = fill ? uint4{0u, 0u, 0u, 0u} : src[u];
+    if (blockIdx.y == 0 && threadIdx.x < (sg.bytes & 15)) {
+        const uint64_t b = units * 16 + threadIdx.x;
+        reinterpret_cast<unsigned char*>(sg.dst)[b] = fill ? (unsigned char)0 : (payload + sg.src_offset)[b];
+    }
+}
+
+void launch_packed_scatter(hipStream_t s, const PackedSeg* table, int n_seg, const unsigned char* payload)
+{
+    if (n_seg > 0) hipLaunchKernelGGL(packed_scatter_kernel, dim3((unsigned)n_seg, kPackSlices), dim3(256), 0, s, table, payload);
+}
+
 // The scalars the host decides on, written straight into pinned host memory, then a sequence number: the host
 // polls that word instead of waiting for a copy command and its completion signal.
 // The scalars the host decides on go straight into pinned host memory, followed by a sequence number: the host polls
@@ -1788,164 +1825,6 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
         hipLaunchKernelGGL((ba_schur_kernel<32>), dim3(n_chunks), dim3(schur_threads(32)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
                            q_pt, q_slot, ar.g, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
     }
-}
-
-// ---- structure-only LM iteration in one launch (see PointsStepArgs) -------------------------------------------------------
-__global__ __launch_bounds__(1024) void ba_points_step_kernel(const PointsStepArgs a, const Proj P, const Publish pb)
-{
-    __shared__ double red[16 * 10];
-    __shared__ double fin[10];
-    double cost_x = 0.0, cost_c = 0.0, mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0, dir_c = 0.0, dmax = 0.0;
-    bool bad = false;
-    for (uint32_t p = threadIdx.x; p < a.n_pt; p += 1024) {
-        const double x[3] = {a.pts[3 * (size_t)p], a.pts[3 * (size_t)p + 1], a.pts[3 * (size_t)p + 2]};
-        // linearisation at x: J_p = A R per observation
-        double c[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-        const uint32_t q0 = a.pt_start[p], q1 = a.pt_start[p + 1];
-        for (uint32_t q = q0; q < q1; q++) {
-            PosePre pr;
-            pose_load(a.campre + kPoseStride * (size_t)a.q_cam[q], pr);
-            double r[4], am[12], D[9];
-            cost_x += residual_ad(pr, x, a.uv[a.pt_obs[q]], P, a.huber_delta, r, am, D);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                double j[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) j[k] = am[i * 3] * pr.R[k] + am[i * 3 + 1] * pr.R[3 + k] + am[i * 3 + 2] * pr.R[6 + k];
-                c[0] += j[0] * j[0]; c[1] += j[0] * j[1]; c[2] += j[0] * j[2]; c[3] += j[1] * j[1]; c[4] += j[1] * j[2]; c[5] += j[2] * j[2];
-                g[0] += j[0] * r[i]; g[1] += j[1] * r[i]; g[2] += j[2] * r[i];
-            }
-        }
-        double sc[3];
-        if (a.init_scale) {
-            sc[0] = a.jacobi ? 1.0 / (1.0 + sqrt(c[0])) : 1.0; sc[1] = a.jacobi ? 1.0 / (1.0 + sqrt(c[3])) : 1.0;
-            sc[2] = a.jacobi ? 1.0 / (1.0 + sqrt(c[5])) : 1.0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) a.sp[3 * (size_t)p + k] = sc[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; k++) sc[k] = a.sp[3 * (size_t)p + k];
-        }
-        const double lam[3] = {point_lambda(c[0], sc[0], a.lm), point_lambda(c[3], sc[1], a.lm), point_lambda(c[5], sc[2], a.lm)};
-        const double m[6] = {c[0] + lam[0], c[1], c[2], c[3] + lam[1], c[4], c[5] + lam[2]};
-        double ci[6];
-        if (!sym3_inverse(m, ci)) bad = true;
-        const double e[3] = {-(ci[0] * g[0] + ci[1] * g[1] + ci[2] * g[2]), -(ci[1] * g[0] + ci[3] * g[1] + ci[4] * g[2]),
-                             -(ci[2] * g[0] + ci[4] * g[1] + ci[5] * g[2])};
-        double xc[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            xc[k] = fmin(fmax(x[k] + e[k], a.bound_lo), a.bound_hi);
-            const double st = xc[k] - x[k];
-            a.pts_out[3 * (size_t)p + k] = xc[k];
-            a.dp[3 * (size_t)p + k] = e[k];
-            a.gp[3 * (size_t)p + k] = g[k];
-            mcc += 0.5 * (lam[k] * e[k] * e[k] - g[k] * e[k]);
-            st2 += st * st;
-            x2 += x[k] * x[k];
-            gd += g[k] * e[k];
-            gm = fmax(gm, fabs(g[k]));
-            dmax = fmax(dmax, fabs(e[k]));
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) { a.C[6 * (size_t)p + k] = c[k]; a.Cinv[6 * (size_t)p + k] = ci[k]; }
-        // the candidate's cost, and direction . gradient there: the first trial of the bounded problem's line search (step size
-        // 1) is this candidate, so the search starts without a launch of its own
-        for (uint32_t q = q0; q < q1; q++) {
-            PosePre pr;
-            pose_load(a.campre + kPoseStride * (size_t)a.q_cam[q], pr);
-            double r[4], am[12], D[9];
-            cost_c += residual_ad(pr, xc, a.uv[a.pt_obs[q]], P, a.huber_delta, r, am, D);
-            double u[3];   // J_p dp = A R dp
-#pragma unroll
-            for (int i = 0; i < 3; i++) u[i] = pr.R[i * 3] * e[0] + pr.R[i * 3 + 1] * e[1] + pr.R[i * 3 + 2] * e[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) dir_c += r[i] * (am[i * 3] * u[0] + am[i * 3 + 1] * u[1] + am[i * 3 + 2] * u[2]);
-        }
-    }
-    cost_x = wave_sum(cost_x); cost_c = wave_sum(cost_c); mcc = wave_sum(mcc); st2 = wave_sum(st2); x2 = wave_sum(x2);
-    gd = wave_sum(gd); gm = wave_max(gm); dir_c = wave_sum(dir_c); dmax = wave_max(dmax);
-    const double badf = wave_max(bad ? 1.0 : 0.0);
-    if (threadIdx.x % kWave == 0) {
-        double* o = red + 10 * (threadIdx.x / kWave);
-        o[0] = cost_x; o[1] = cost_c; o[2] = mcc; o[3] = st2; o[4] = x2; o[5] = gd; o[6] = gm; o[7] = badf; o[8] = dir_c; o[9] = dmax;
-    }
-    __syncthreads();
-    if (threadIdx.x < 10) {
-        const int k = threadIdx.x;
-        double v = 0.0;
-        for (int w = 0; w < 16; w++) v = (k == 6 || k == 7 || k == 9) ? fmax(v, red[10 * w + k]) : v + red[10 * w + k];
-        if (k < 2) v *= 0.5;
-        fin[k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double* sc = a.scal;
-        sc[SC_COST_X] = fin[0]; *a.cost_x_out = fin[0]; sc[SC_CAND_COST] = fin[1]; sc[SC_MCC_PTS] = fin[2]; sc[SC_STEP2_PTS] = fin[3]; sc[SC_X2_PTS] = fin[4];
-        sc[SC_GDOT_PTS] = fin[5]; sc[SC_GMAX_PTS] = fin[6]; sc[SC_STOP] = 0.0;
-        sc[SC_MCC_CAM] = 0.0; sc[SC_STEP2_CAM] = 0.0; sc[SC_X2_CAM] = 0.0; sc[SC_GDOT_CAM] = 0.0; sc[SC_GMAX_CAM] = 0.0;
-        sc[SC_LIN_ITERS] = 0.0; sc[SC_LIN_RESID] = 0.0; sc[SC_LIN_STATUS] = 0.0; sc[SC_SCHUR_STATUS] = fin[7];
-        sc[SC_LS_COST] = fin[1]; sc[SC_LS_DIR] = fin[8]; sc[SC_LS_STEP2] = fin[3]; sc[SC_LS_DMAX] = fin[9];   // the search's trial at step size 1
-        const double mc = fin[2], cand = fin[1];
-        const bool ok = fin[7] == 0.0 && isfinite(mc) && isfinite(cand) && mc > 0.0 && cand <= a.x_cost + 1e-4 * fin[5];
-        sc[SC_GATE] = (a.gate_enabled && ok && (a.x_cost - cand) / mc > a.min_relative_decrease) ? 1.0 : 0.0;
-    }
-    publish_tail(pb);
-}
-
-void launch_points_step(hipStream_t s, const PointsStepArgs& a, const Proj& P, double* pub_src, int n_pub, int clear_first, int clear_n,
-                        double* host_dst, unsigned long long* host_seq, unsigned long long seq)
-{
-    hipLaunchKernelGGL(ba_points_step_kernel, dim3(1), dim3(1024), 0, s, a, P, Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
-}
-
-// One line-search trial of a structure-only problem in ONE launch (what ba_ls_candidate, ba_pose_prepare, ba_ls_eval and
-// ba_ls_sums do for the general case): candidate x+ = clamp(x + a dp) into pts_out, its cost, direction . gradient,
-// |x+ - x|^2 and |dp|_inf into scal[SC_LS_*], published.  The per-frame call of the reference's schedule needs the search in
-// most of its iterations (two trials each): eight launches per iteration become two.
-__global__ __launch_bounds__(1024) void ba_points_ls_kernel(const PointsStepArgs a, const Proj P, const double step, const Publish pb)
-{
-    __shared__ double red[16 * 4];
-    double rho = 0.0, dir = 0.0, st2 = 0.0, dmax = 0.0;
-    for (uint32_t p = threadIdx.x; p < a.n_pt; p += 1024) {
-        double x[3], e[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double x0 = a.pts[3 * (size_t)p + k];
-            e[k] = a.dp[3 * (size_t)p + k];
-            x[k] = fmin(fmax(x0 + step * e[k], a.bound_lo), a.bound_hi);   // ParameterBlock::Plus projects onto the bounds
-            a.pts_out[3 * (size_t)p + k] = x[k];
-            st2 += (x[k] - x0) * (x[k] - x0);
-            dmax = fmax(dmax, fabs(e[k]));
-        }
-        for (uint32_t q = a.pt_start[p]; q < a.pt_start[p + 1]; q++) {
-            PosePre pr;
-            pose_load(a.campre + kPoseStride * (size_t)a.q_cam[q], pr);
-            double r[4], am[12], D[9];
-            rho += residual_ad(pr, x, a.uv[a.pt_obs[q]], P, a.huber_delta, r, am, D);
-            double u[3];   // J_p dp = A R dp
-#pragma unroll
-            for (int i = 0; i < 3; i++) u[i] = pr.R[i * 3] * e[0] + pr.R[i * 3 + 1] * e[1] + pr.R[i * 3 + 2] * e[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) dir += r[i] * (am[i * 3] * u[0] + am[i * 3 + 1] * u[1] + am[i * 3 + 2] * u[2]);
-        }
-    }
-    rho = wave_sum(rho); dir = wave_sum(dir); st2 = wave_sum(st2); dmax = wave_max(dmax);
-    if (threadIdx.x % kWave == 0) { double* o = red + 4 * (threadIdx.x / kWave); o[0] = rho; o[1] = dir; o[2] = st2; o[3] = dmax; }
-    __syncthreads();
-    static_assert(SC_LS_DIR == SC_LS_COST + 1 && SC_LS_STEP2 == SC_LS_COST + 2 && SC_LS_DMAX == SC_LS_COST + 3, "line-search slots");
-    if (threadIdx.x < 4) {
-        double v = 0.0;
-        for (int w = 0; w < 16; w++) v = threadIdx.x == 3 ? fmax(v, red[4 * w + 3]) : v + red[4 * w + threadIdx.x];
-        a.scal[SC_LS_COST + threadIdx.x] = threadIdx.x == 0 ? 0.5 * v : v;
-    }
-    publish_tail(pb);
-}
-
-void launch_points_ls(hipStream_t s, const PointsStepArgs& a, const Proj& P, double step, double* pub_src, int n_pub, double* host_dst,
-                      unsigned long long* host_seq, unsigned long long seq)
-{
-    hipLaunchKernelGGL(ba_points_ls_kernel, dim3(1), dim3(1024), 0, s, a, P, step, Publish{pub_src, host_dst, host_seq, seq, n_pub, 0, 0});
 }
 
 // ---- line search trial (TrustRegionMinimizer::DoLineSearch on bounded problems; run only when the full step fails the

@@ -147,6 +147,13 @@ struct soslam_ba {
     double* host_scal = nullptr;        // host_raw + 4
     unsigned long long* host_seq = nullptr;   // behind host_raw: sequence number of the last publication
     unsigned long long publish_seq = 0;
+    unsigned char* up_host[2] = {nullptr, nullptr};   // pinned staging of the packed uploads (PackedSeg table, then payloads): the index
+    size_t up_host_bytes[2] = {0, 0};                 // arrays, and - their kernel may still be reading - the table of the fills
+    double* ps_host = nullptr;          // pinned: record (PSV_COUNT) + sequence word + iteration log of the resident structure-only solve
+    int ps_host_entries = 0;
+    DevBuf<double> ps_log;              // the same log on the device while the kernel runs
+    DevBuf<double> ps_sync;             // its grid barrier: [2][kPointsOnlyMax / 64][16] partial-sum records, then the arrival counter
+    unsigned long long ps_sync_base = 0;   // value of that counter between launches
 
     // multi-GPU
     soslam_allreduce_fn allreduce = nullptr;
@@ -176,6 +183,7 @@ struct soslam_ba {
     bool points_only_ready = false;     // structure-only path: both pose tables / camera buffers hold the constant poses, dc_full is zero
     int invalid_run = 0;
     std::vector<soslam_ba_iteration> log;
+    std::vector<std::vector<uint32_t>> h_blk_contrib, h_cam_contrib;   // set-up scratch (build_problem), kept for its capacity
 
     // profiling
     std::vector<hipEvent_t> ev_pool;
@@ -195,6 +203,8 @@ struct soslam_ba {
     {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         if (host_raw) (void)hipHostFree(host_raw);
+        if (ps_host) (void)hipHostFree(ps_host);
+        for (unsigned char* u : up_host) if (u) (void)hipHostFree(u);
         if (stage) (void)hipHostFree(stage);
         rccl_comm_destroy(rccl);
         if (fstream) { (void)hipStreamSynchronize(fstream); (void)hipStreamDestroy(fstream); }
@@ -289,6 +299,69 @@ void parallel_ranges(size_t n, size_t work, F&& f)
     }
     for (auto& x : th) x.join();
 }
+
+// Uploads of one set_problem, collected: up to kPackedUploadMax bytes go as ONE kernel reading a pinned staging buffer
+// (launch_packed_scatter), more as one copy command per array.  The staging buffer is free again when the stream has been
+// synchronised (build_problem ends on that).
+constexpr size_t kPackedUploadMax = 4u << 20;
+struct UploadBatch {
+    struct Seg { void* dst; const void* src; size_t bytes; };
+    std::vector<Seg> segs;
+    size_t total = 0;
+    template <class T>
+    int add(DevBuf<T>& b, const std::vector<T>& v)
+    {
+        SOSLAM_CHECK(b.alloc(v.size()));
+        if (!v.empty()) { segs.push_back(Seg{b.p, v.data(), v.size() * sizeof(T)}); total += (v.size() * sizeof(T) + 15) & ~(size_t)15; }
+        return SOSLAM_OK;
+    }
+    template <class T>
+    int add_zero(DevBuf<T>& b)
+    {
+        if (b.n) segs.push_back(Seg{b.p, nullptr, b.n * sizeof(T)});
+        return SOSLAM_OK;
+    }
+    int flush(soslam_ba* h, hipStream_t s, int region)
+    {
+        static const bool off = [] { const char* e = getenv("SOSLAM_NO_PACKED_UPLOAD"); return e && *e && *e != '0'; }();
+        if (segs.empty()) return SOSLAM_OK;
+        if (off || total > kPackedUploadMax) {
+            for (const Seg& g : segs) {
+                if (g.src) SOSLAM_HIP_CHECK(hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, s));
+                else SOSLAM_HIP_CHECK(hipMemsetAsync(g.dst, 0, g.bytes, s));
+            }
+            segs.clear(); total = 0;
+            return SOSLAM_OK;
+        }
+        const size_t table_bytes = (segs.size() * sizeof(PackedSeg) + 15) & ~(size_t)15, need = table_bytes + total;
+        if (need > h->up_host_bytes[region]) {
+            if (h->up_host[region]) (void)hipHostFree(h->up_host[region]);
+            h->up_host[region] = nullptr; h->up_host_bytes[region] = 0;
+            const size_t cap = std::max<size_t>(need + need / 4, 1u << 16);
+            SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->up_host[region]), cap, hipHostMallocDefault));
+            h->up_host_bytes[region] = cap;
+        }
+        PackedSeg* table = reinterpret_cast<PackedSeg*>(h->up_host[region]);
+        unsigned char* payload = h->up_host[region] + table_bytes;
+        size_t off_b = 0;
+        int n_seg = 0;
+        for (const Seg& g : segs) {
+            if (g.src) {
+                std::memcpy(payload + off_b, g.src, g.bytes);
+                table[n_seg++] = PackedSeg{g.dst, (uint64_t)off_b, (uint64_t)g.bytes};
+                off_b += (g.bytes + 15) & ~(size_t)15;
+            } else if (g.bytes > (1u << 20)) {
+                SOSLAM_HIP_CHECK(hipMemsetAsync(g.dst, 0, g.bytes, s));   // a large fill is the copy engine's
+            } else {
+                table[n_seg++] = PackedSeg{g.dst, ~0ull, (uint64_t)g.bytes};
+            }
+        }
+        launch_packed_scatter(s, table, n_seg, payload);
+        SOSLAM_HIP_CHECK(hipGetLastError());
+        segs.clear(); total = 0;
+        return SOSLAM_OK;
+    }
+};
 
 int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, const uint32_t* ocam,
                   const uint32_t* opt_, const float* ouv, const uint8_t* fixed)
@@ -561,7 +634,13 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     std::vector<uint32_t> pair_row;                         // kmax <= 10: [batch][120], see launch_schur
     std::vector<uint32_t> chunk_slab;                       // offset of each chunk's window in the slab
     std::vector<uint32_t> chunk_cam;                        // [chunk][K] camera of each window slot
-    std::vector<std::vector<uint32_t>> blk_contrib(h->n_blocks), cam_contrib(nf);
+    // (the lists of lists stay with the handle: a kept handle's next window re-uses their storage)
+    std::vector<std::vector<uint32_t>>& blk_contrib = h->h_blk_contrib;
+    std::vector<std::vector<uint32_t>>& cam_contrib = h->h_cam_contrib;
+    if (blk_contrib.size() < h->n_blocks) blk_contrib.resize(h->n_blocks);
+    if (cam_contrib.size() < nf) cam_contrib.resize(nf);
+    for (uint32_t b = 0; b < h->n_blocks; b++) blk_contrib[b].clear();
+    for (uint32_t f = 0; f < nf; f++) cam_contrib[f].clear();
     uint64_t slab_count = 0;
     std::vector<uint8_t> q_slot(n_obs, 255);
     std::vector<uint32_t> chunk_p_range, chunk_local;       // [chunk][2] point range, [chunk][K] free index of each window slot
@@ -636,6 +715,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
         }
         close_chunk(n_short);
     }
+    SETUP_MARK("chunk windows");
     if (K <= 10) pair_row.assign(batches.size() * (size_t)kS10PairsPerBatch, 0xFFFFFFFFu);
     parallel_ranges(chunks.size(), n_obs, [&](size_t c_lo, size_t c_hi, unsigned) {
         for (size_t ci = c_lo; ci < c_hi; ci++) {
@@ -667,6 +747,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
             }
         }
     });
+    SETUP_MARK("window slots");
     // long-track points: one slab slot per camera pair and per camera, through the same contribution lists
     std::vector<LongPoint> long_pts;
     std::vector<uint32_t> lo_row, lo_cam, lo_cam_off, pair_a, pair_b, pair_off;
@@ -726,7 +807,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     h->n_batches = (uint32_t)batches.size();
     h->n_point_blocks = backsub_blocks(n_pt);   // ba_backsub writes one partial record per workgroup
 
-    SETUP_MARK("chunks");
+    SETUP_MARK("contribution lists");
     // solver choice
     h->bw = 0;
     for (uint32_t b = 0; b < h->n_blocks; b++) h->bw = std::max<int>(h->bw, (int)(h->h_blk_col[b] - h->h_blk_row[b]));
@@ -772,43 +853,45 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
 
     SETUP_MARK("solver choice");
     // uploads
-    SOSLAM_CHECK(h->uv.upload(uv, s));
-    SOSLAM_CHECK(h->obs_pt.upload(v_obs_pt, s));
-    SOSLAM_CHECK(h->q_cam.upload(q_cam, s));
-    SOSLAM_CHECK(h->pt_obs.upload(pt_obs, s));
-    SOSLAM_CHECK(h->tiles.upload(tiles, s));
-    SOSLAM_CHECK(h->cam_tile_start.upload(cam_tile_start, s));
-    SOSLAM_CHECK(h->cam_free.upload(h->h_cam_free, s));
-    SOSLAM_CHECK(h->pt_start.upload(pt_start, s));
-    SOSLAM_CHECK(h->q_pt.upload(q_pt, s));
-    SOSLAM_CHECK(h->q_slot.upload(q_slot, s));
-    SOSLAM_CHECK(h->chunks.upload(chunks, s));
-    SOSLAM_CHECK(h->batches.upload(batches, s));
-    SOSLAM_CHECK(h->pair_row.upload(pair_row, s));
-    SOSLAM_CHECK(h->chunk_slab.upload(chunk_slab, s));
-    SOSLAM_CHECK(h->chunk_cam.upload(chunk_cam, s));
-    SOSLAM_CHECK(h->free_cam.upload(free_cam, s));
-    SOSLAM_CHECK(h->long_pts.upload(long_pts, s));
-    SOSLAM_CHECK(h->lo_row.upload(lo_row, s));
-    SOSLAM_CHECK(h->lo_cam.upload(lo_cam, s));
-    SOSLAM_CHECK(h->lo_cam_off.upload(lo_cam_off, s));
-    SOSLAM_CHECK(h->pair_a.upload(pair_a, s));
-    SOSLAM_CHECK(h->pair_b.upload(pair_b, s));
-    SOSLAM_CHECK(h->pair_off.upload(pair_off, s));
+    UploadBatch up;
+    SOSLAM_CHECK(up.add(h->uv, uv));
+    SOSLAM_CHECK(up.add(h->obs_pt, v_obs_pt));
+    SOSLAM_CHECK(up.add(h->q_cam, q_cam));
+    SOSLAM_CHECK(up.add(h->pt_obs, pt_obs));
+    SOSLAM_CHECK(up.add(h->tiles, tiles));
+    SOSLAM_CHECK(up.add(h->cam_tile_start, cam_tile_start));
+    SOSLAM_CHECK(up.add(h->cam_free, h->h_cam_free));
+    SOSLAM_CHECK(up.add(h->pt_start, pt_start));
+    SOSLAM_CHECK(up.add(h->q_pt, q_pt));
+    SOSLAM_CHECK(up.add(h->q_slot, q_slot));
+    SOSLAM_CHECK(up.add(h->chunks, chunks));
+    SOSLAM_CHECK(up.add(h->batches, batches));
+    SOSLAM_CHECK(up.add(h->pair_row, pair_row));
+    SOSLAM_CHECK(up.add(h->chunk_slab, chunk_slab));
+    SOSLAM_CHECK(up.add(h->chunk_cam, chunk_cam));
+    SOSLAM_CHECK(up.add(h->free_cam, free_cam));
+    SOSLAM_CHECK(up.add(h->long_pts, long_pts));
+    SOSLAM_CHECK(up.add(h->lo_row, lo_row));
+    SOSLAM_CHECK(up.add(h->lo_cam, lo_cam));
+    SOSLAM_CHECK(up.add(h->lo_cam_off, lo_cam_off));
+    SOSLAM_CHECK(up.add(h->pair_a, pair_a));
+    SOSLAM_CHECK(up.add(h->pair_b, pair_b));
+    SOSLAM_CHECK(up.add(h->pair_off, pair_off));
     SOSLAM_CHECK(h->long_wy.alloc(lo_row.size() * 36));
-    SOSLAM_CHECK(h->blk_contrib_ptr.upload(bc_ptr, s));
-    SOSLAM_CHECK(h->blk_contrib_off.upload(bc_off, s));
-    SOSLAM_CHECK(h->cam_contrib_ptr.upload(cc_ptr, s));
-    SOSLAM_CHECK(h->cam_contrib_off.upload(cc_off, s));
+    SOSLAM_CHECK(up.add(h->blk_contrib_ptr, bc_ptr));
+    SOSLAM_CHECK(up.add(h->blk_contrib_off, bc_off));
+    SOSLAM_CHECK(up.add(h->cam_contrib_ptr, cc_ptr));
+    SOSLAM_CHECK(up.add(h->cam_contrib_off, cc_off));
     SOSLAM_CHECK(h->slab.alloc((size_t)slab_count));
-    SOSLAM_CHECK(h->diag_block.upload(diag_block, s));
-    SOSLAM_CHECK(h->row_ptr.upload(row_ptr, s));
-    SOSLAM_CHECK(h->ent_col.upload(ent_col, s));
-    SOSLAM_CHECK(h->ent_blk.upload(ent_blk, s));
-    SOSLAM_CHECK(h->ent_trans.upload(ent_trans, s));
-    SOSLAM_CHECK(h->blk_row.upload(h->h_blk_row, s));
-    SOSLAM_CHECK(h->blk_col.upload(h->h_blk_col, s));
+    SOSLAM_CHECK(up.add(h->diag_block, diag_block));
+    SOSLAM_CHECK(up.add(h->row_ptr, row_ptr));
+    SOSLAM_CHECK(up.add(h->ent_col, ent_col));
+    SOSLAM_CHECK(up.add(h->ent_blk, ent_blk));
+    SOSLAM_CHECK(up.add(h->ent_trans, ent_trans));
+    SOSLAM_CHECK(up.add(h->blk_row, h->h_blk_row));
+    SOSLAM_CHECK(up.add(h->blk_col, h->h_blk_col));
 
+    SOSLAM_CHECK(up.flush(h, s, 0));
     SETUP_MARK("uploads");
     // work buffers
     for (int i = 0; i < 2; i++) {
@@ -839,8 +922,9 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->part.alloc((size_t)h->n_point_blocks * 5));
     SOSLAM_CHECK(h->lin_resid.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->lin_work.alloc(std::max({pcg_work_count(nf), pcg_band_work_count(nf), pcg_multi_work_count(nf)})));
-    SOSLAM_CHECK(h->dc_free.zero(s)); SOSLAM_CHECK(h->Cinv.zero(s));
-    SOSLAM_CHECK(h->lin_resid.zero(s));
+    UploadBatch zeros;   // fills, as one more kernel
+    SOSLAM_CHECK(zeros.add_zero(h->dc_free)); SOSLAM_CHECK(zeros.add_zero(h->Cinv));
+    SOSLAM_CHECK(zeros.add_zero(h->lin_resid));
     if (h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY) {
         const size_t n6 = (size_t)nf * 6;
         SOSLAM_CHECK(h->dense.alloc(std::max(n6 * n6 + (size_t)div_up(n6, 32) * 32 * 32 + 1024, dense_inverse_fits(nf) ? dense_inverse_count(nf) : (size_t)0)));
@@ -925,7 +1009,8 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     h->reduce_main = (uint64_t)h->n_blocks * 36 + (uint64_t)nf * 18 + 4;
     h->reduce_count = h->reduce_main + SC_COUNT;
     SOSLAM_CHECK(h->reduce_own.alloc(h->reduce_count));
-    SOSLAM_CHECK(h->reduce_own.zero(s));
+    SOSLAM_CHECK(zeros.add_zero(h->reduce_own));
+    SOSLAM_CHECK(zeros.flush(h, s, 1));
     h->reduce = h->reduce_own.p;
     if (!h->host_raw) {
         SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_raw), sizeof(double) * (SC_COUNT + 4 + 1), hipHostMallocDefault));
@@ -1590,6 +1675,113 @@ int line_search(soslam_ba* h, const StepScalars& sc, double* step_size, double* 
     return SOSLAM_OK;
 }
 
+// Structure-only problems (the per-frame call, /root/reference/src/slam.cpp:123): the whole loop below in ONE launch, controller and
+// line search included (ba_points.hip: ba_points_solve).  The host enqueues it, polls one sequence word and copies the record
+// and the iteration log out of pinned memory.  Verbose and per-stage profiling runs keep the host loop (one launch per
+// iteration and per trial), as does SOSLAM_NO_RESIDENT_SOLVE=1.
+bool resident_solve(const soslam_ba* h, int max_it)
+{
+    static const bool off = [] { const char* e = getenv("SOSLAM_NO_RESIDENT_SOLVE"); return e && *e && *e != '0'; }();
+    return !off && points_only(h) && max_it > 0 && !h->opt.verbose && !h->opt.profile_stages;
+}
+
+static_assert(sizeof(soslam_ba_iteration) == sizeof(double) * kPointsLogDoubles, "the device writes the log in this layout");
+static_assert(kPointsTermMaxIterations == SOSLAM_TERM_MAX_ITERATIONS && kPointsTermParameter == SOSLAM_TERM_PARAMETER_TOLERANCE &&
+              kPointsTermFunction == SOSLAM_TERM_FUNCTION_TOLERANCE && kPointsTermGradient == SOSLAM_TERM_GRADIENT_TOLERANCE &&
+              kPointsTermMinRadius == SOSLAM_TERM_MIN_RADIUS && kPointsTermInvalid == SOSLAM_TERM_INVALID_STEPS &&
+              kPointsTermTime == SOSLAM_TERM_TIME, "termination codes of the device controller");
+
+int run_points_resident(soslam_ba* h, int max_it, bool check, soslam_ba_summary* out)
+{
+    const soslam_ba_options& o = h->opt;
+    hipStream_t s = h->stream;
+    soslam_ba_summary sum{};
+    sum.linear_solver = h->solver;
+    sum.setup_seconds = h->setup_seconds;
+    const double t0 = now_sec();
+    h->log.clear();
+    const int entries = max_it + 1;
+    constexpr int kHead = PSV_COUNT + 1;   // record, sequence word
+    if (entries > h->ps_host_entries) {
+        if (h->ps_host) (void)hipHostFree(h->ps_host);
+        h->ps_host = nullptr; h->ps_host_entries = 0;
+        const int cap = std::max(entries, 64);
+        SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->ps_host), sizeof(double) * ((size_t)kHead + (size_t)cap * kPointsLogDoubles),
+                                       hipHostMallocDefault));
+        h->ps_host_entries = cap;
+        *reinterpret_cast<unsigned long long*>(h->ps_host + PSV_COUNT) = 0;
+    }
+    SOSLAM_CHECK(h->ps_log.alloc((size_t)h->ps_host_entries * kPointsLogDoubles));
+    if (!h->points_only_ready) {
+        launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);
+        launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre_c.p);
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->cams[h->cur ^ 1].p, h->cams[h->cur].p, sizeof(double) * 6 * h->n_cam, hipMemcpyDeviceToDevice, s));
+        SOSLAM_CHECK(h->dc_full.zero(s));
+        h->points_only_ready = true;
+    }
+    PointsStepArgs a{};
+    a.n_pt = h->n_pt; a.pt_start = h->pt_start.p; a.pt_obs = h->pt_obs.p; a.q_cam = h->q_cam.p; a.uv = h->uv.p;
+    a.campre = h->campre.p; a.pts = h->pts[h->cur].p; a.pts_out = h->pts[h->cur ^ 1].p; a.dp = h->dp.p;
+    a.C = h->C.p; a.gp = h->gp.p; a.sp = h->sp.p; a.Cinv = h->Cinv.p; a.huber_delta = o.huber_delta;
+    a.bound_lo = o.lower_bound; a.bound_hi = o.upper_bound; a.jacobi = o.jacobi_scaling; a.scal = h->scalp(); a.cost_x_out = h->tail();
+    PointsSolveCtl c{};
+    c.pts[0] = h->pts[0].p; c.pts[1] = h->pts[1].p;
+    c.cur = h->cur; c.invalid_run = h->invalid_run; c.init_scale = h->scale_init ? 0 : 1; c.x_cost_known = h->x_cost_known ? 1 : 0;
+    c.radius = h->radius; c.decrease_factor = h->decrease_factor; c.x_cost = h->x_cost;
+    c.max_it = max_it; c.check = check ? 1 : 0; c.constrained = is_constrained(h) ? 1 : 0;
+    c.lm_lo = o.min_lm_diagonal; c.lm_hi = o.max_lm_diagonal;
+    c.min_radius = o.min_radius; c.max_radius = o.max_radius; c.min_relative_decrease = o.min_relative_decrease;
+    c.gradient_tolerance = o.gradient_tolerance; c.parameter_tolerance = o.parameter_tolerance; c.function_tolerance = o.function_tolerance;
+    c.max_ticks = (check && o.max_solver_time_seconds > 0.0) ? std::max<long long>(1, (long long)(o.max_solver_time_seconds * 1e8)) : 0;
+    c.log = h->ps_log.p;
+    constexpr size_t kSyncRecords = 2 * (size_t)(kPointsOnlyMax / 64) * 16;
+    if (!h->ps_sync.p) {
+        SOSLAM_CHECK(h->ps_sync.alloc(kSyncRecords + 16));
+        SOSLAM_CHECK(h->ps_sync.zero(s));
+        h->ps_sync_base = 0;
+    }
+    c.n_wg = (int)((h->n_pt + 63) / 64);
+    c.sync_records = h->ps_sync.p;
+    c.sync_counter = reinterpret_cast<unsigned long long*>(h->ps_sync.p + kSyncRecords);
+    c.sync_base = h->ps_sync_base;
+    c.host_record = h->ps_host;
+    c.host_seq = reinterpret_cast<unsigned long long*>(h->ps_host + PSV_COUNT);
+    c.host_log = h->ps_host + kHead;
+    c.seq = ++h->publish_seq;
+    h->scale_init = true;
+    launch_points_solve(s, a, h->proj, c);
+    SOSLAM_CHECK(wait_host_seq(h, c.host_seq, c.seq));
+    const double* r = h->ps_host;
+    h->ps_sync_base += (unsigned long long)r[PSV_PASSES] * (unsigned long long)c.n_wg;
+    if (r[PSV_ERROR] == 2.0) {
+        // a workgroup never arrived at the grid barrier: the counter is no longer what the host thinks it is
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        SOSLAM_CHECK(h->ps_sync.zero(s));
+        h->ps_sync_base = 0;
+        set_last_error("the structure-only solve's grid barrier timed out");
+        return SOSLAM_ERR_HIP;
+    }
+    if (r[PSV_ERROR] != 0.0) {
+        set_last_error("non-finite cost at the initial point");
+        return SOSLAM_ERR_NON_FINITE;
+    }
+    h->radius = r[PSV_RADIUS]; h->decrease_factor = r[PSV_DECREASE]; h->x_cost = r[PSV_X_COST]; h->x_cost_known = true;
+    h->cur = (int)r[PSV_CUR]; h->invalid_run = (int)r[PSV_INVALID_RUN];
+    h->linearized = true; h->campre_current = false;
+    const int n_log = (int)r[PSV_N_LOG];
+    h->log.resize((size_t)n_log);
+    if (n_log) std::memcpy(h->log.data(), h->ps_host + kHead, sizeof(soslam_ba_iteration) * (size_t)n_log);
+    sum.iterations = (int)r[PSV_ITERATIONS];
+    sum.accepted = (int)r[PSV_ACCEPTED];
+    sum.termination = (int)r[PSV_TERMINATION];
+    sum.line_search_steps = (int)r[PSV_LS_STEPS];
+    sum.initial_cost = r[PSV_INITIAL_COST];
+    sum.final_cost = h->x_cost;
+    sum.solve_seconds = now_sec() - t0;
+    if (out) *out = sum;
+    return SOSLAM_OK;
+}
+
 // The Levenberg-Marquardt loop.  fixed_count >= 0: exactly that many iterations, no termination tests.
 int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
 {
@@ -1600,6 +1792,7 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
     const soslam_ba_options& o = h->opt;
     const bool check = fixed_count < 0 && o.check_termination;
     const int max_it = fixed_count >= 0 ? fixed_count : o.max_iterations;
+    if (resident_solve(h, max_it)) return run_points_resident(h, max_it, check, out);
     soslam_ba_summary sum{};
     sum.linear_solver = h->solver;
     sum.setup_seconds = h->setup_seconds;

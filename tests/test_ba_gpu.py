@@ -258,6 +258,47 @@ def test_structure_only_single_fixed_camera(gpu, oracle_lib, prob1):
     np.testing.assert_allclose(pts, opts_, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("bound", [1e4, 3.0, float("inf")])
+def test_structure_only_solve_resident_on_the_device_matches_the_oracle(gpu, oracle_lib, bound):
+    """The per-frame call of the reference's schedule (slam.cpp:123: one constant frame, its ~1 000 points) runs as ONE launch:
+    trust-region controller, termination tests and Ceres' Armijo / cubic-interpolation line search on the device
+    (ba_points.hip: ba_points_solve).  Same iteration log as the oracle's - radius, acceptance, costs, step norms, number of
+    line-search steps - with the reference's bounds (1e4: the search runs on a few iterations), with a box the start lies outside of
+    (3: every step is projected back, every iteration searches through several contractions - three-sample interpolation, the
+    quintic and its quartic derivative's roots - and fails), and without bounds (Ceres does not search then).  The host-driven loop (one launch per iteration
+    and per trial; profile_stages selects it) must give the same log."""
+    ba, synth, L = gpu
+    p = synth.generate_ba(None, n_cam=1, n_pt=1000, track_mode=0, track_len=1)
+    kw = dict(max_iterations=12, lower_bound=-bound, upper_bound=bound)
+    ocams, opts_, osum, olog = _oracle_solve(oracle_lib, p, **kw)
+    logs = []
+    for host_loop in (0, 1):
+        with ba.BundleAdjustment(ba.default_options(profile_stages=host_loop, **kw)) as h:
+            h.load(p)
+            summ = h.solve()
+            cams, pts = h.get_state()
+            log = h.iteration_log()
+            again = h.solve()           # at the minimum: the kept state (radius, cost) carries over
+        logs.append(log)
+        assert summ.iterations == osum.iterations and summ.termination == osum.termination
+        assert summ.line_search_steps == osum.line_search_steps
+        assert osum.line_search_steps > (24 if bound == 3.0 else 0 if bound == 1e4 else -1) and (osum.line_search_steps == 0) == bool(np.isinf(bound))
+        assert [e.accepted for e in log] == [e.accepted for e in olog] and [e.valid for e in log] == [e.valid for e in olog]
+        np.testing.assert_allclose([e.cost for e in log], [e.cost for e in olog], rtol=1e-9)
+        np.testing.assert_allclose([e.radius for e in log], [e.radius for e in olog], rtol=1e-6)
+        np.testing.assert_allclose([e.step_norm for e in log[1:]], [e.step_norm for e in olog[1:]], rtol=1e-5, atol=1e-12)
+        # (the host-driven loop learns the gradient at an accepted point with the NEXT iteration's linearisation: its last entry
+        # keeps the gradient of the point before; the device loop has it with the trial's sums)
+        ng = len(log) - host_loop
+        np.testing.assert_allclose([e.gradient_max_norm for e in log[:ng]], [e.gradient_max_norm for e in olog[:ng]], rtol=1e-5, atol=1e-9)
+        assert summ.final_cost == pytest.approx(osum.final_cost, rel=1e-9)
+        np.testing.assert_array_equal(cams, p.poses_cw())
+        np.testing.assert_allclose(pts, opts_, rtol=1e-7, atol=1e-7)
+        assert again.initial_cost == pytest.approx(summ.final_cost, rel=1e-12) and again.final_cost <= again.initial_cost
+    np.testing.assert_allclose([e.cost for e in logs[0]], [e.cost for e in logs[1]], rtol=1e-10)
+    np.testing.assert_allclose([e.radius for e in logs[0]], [e.radius for e in logs[1]], rtol=1e-8)
+
+
 def test_observation_order_invariance(gpu, prob1):
     """The solver sorts observations itself (camera-major, point-major): a shuffled input gives the same
     reduced system to rounding and the same solution."""
