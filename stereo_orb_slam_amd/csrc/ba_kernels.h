@@ -162,6 +162,7 @@ void launch_status_poison(hipStream_t s, double* scal);
 // The index of a window of a few thousand observations is ~35 arrays of a few KB: as separate copy commands they cost more than
 // the index takes to build.  The host packs them into one pinned buffer (table of segments, then the 16-byte aligned payloads)
 // and ONE kernel reads that buffer over the link and writes every array where it belongs (src_offset = ~0: fill with zeros).
+// With payload == nullptr the offsets are source ADDRESSES: the same kernel gathers device arrays into pinned host memory.
 struct PackedSeg { void* dst; uint64_t src_offset; uint64_t bytes; };
 void launch_packed_scatter(hipStream_t s, const PackedSeg* table, int n_seg, const unsigned char* payload);
 
@@ -226,7 +227,8 @@ void launch_points_solve(hipStream_t s, const PointsStepArgs& a, const Proj& P, 
 // trial point x+ = Plus(x, a delta): cameras x + a dc, points projected onto the box; ls_part[block][2] = {|x+ - x|^2 of the
 // block's points, max |delta_i| of the block}
 void launch_ls_candidate(hipStream_t s, uint32_t n_cam, uint32_t n_pt, const double* cams, const double* pts, const double* dc_full,
-                         const double* dp, double a, double bound_lo, double bound_hi, double* cams_out, double* pts_out, double* ls_part);
+                         const double* dp, double a, double bound_lo, double bound_hi, double* cams_out, double* pts_out, double* ls_part,
+                         double* campre_c /* the trial's pose table, written by the same launch */);
 inline uint32_t ls_candidate_blocks(uint32_t n_pt) { return (n_pt * 3 + 255) / 256 + 1; }
 // cost and direction . gradient at the trial point (campre_c, pts_c = its pose table and points; the direction is the FULL
 // step dc_full / dp): per tile [rho sum, sum of r~^T (J~_c dc + J~_p dp)] into tile_part2[tile][2]
@@ -256,7 +258,8 @@ void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, cons
                          const uint32_t* cam_tile_start, const double* tile_part /* ba_linearize's per-tile camera sums: the kernel
                          forms each camera's own block B and gradient g_c from them (T applied once per camera) */,
                          double* S, double* rhs, double* diagB, double* gc_red,
-                         const double* cost_in, double* cost_out /* cost_out = cost_in: this rank's cost joins the reduce payload */);
+                         const double* cost_in, double* cost_out /* cost_out = cost_in: this rank's cost joins the reduce payload */,
+                         const CamDamp* damp = nullptr /* one rank, dense solve: the camera damping too (no ba_cam_damp launch) */);
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,
                      LmDiag lm, const int32_t* diag_block, double* S, double* lc);

@@ -1357,7 +1357,8 @@ __global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, 
                                                              const double* __restrict__ tile_part,
                                                              double* __restrict__ S, double* __restrict__ rhs,
                                                              double* __restrict__ diagB, double* __restrict__ gc_red,
-                                                             const double* __restrict__ cost_in, double* __restrict__ cost_out)
+                                                             const double* __restrict__ cost_in, double* __restrict__ cost_out,
+                                                             const CamDamp damp, const int with_damp)
 {
     __shared__ double t0[36], t1[36];
     __shared__ double bt[36], gt[6], Tm[36], Bc[36], gc6[6];   // the camera's own block from the linearisation's tile sums
@@ -1415,7 +1416,21 @@ __global__ __launch_bounds__(64) void ba_schur_reduce_kernel(uint32_t n_blocks, 
             // a same-camera block is symmetric only to rounding after the two products: its lower entries take the
             // upper ones, so every consumer that mirrors or reads either triangle sees the same bits
             const double w = (fa == fb && r > c) ? t0[c * 6 + r] : v;
-            S[36 * (size_t)id + t] = (fa == fb ? Bc[t] : 0.0) - w;
+            double out = (fa == fb ? Bc[t] : 0.0) - w;
+            if (with_damp && fa == fb && r == c) {
+                // the camera damping (what ba_cam_damp does in a launch of its own after an all-reduce): one rank, no band factor
+                const uint32_t i = 6 * fa + (uint32_t)r;
+                const double d = Bc[t];
+                double sc = damp.sc[i];
+                if (damp.init_scale) {
+                    sc = damp.jacobi ? 1.0 / (1.0 + sqrt(d)) : 1.0;
+                    damp.sc[i] = sc;
+                }
+                const double lam = point_lambda(d, sc, damp.lm);
+                damp.lc[i] = lam;
+                out += lam;
+            }
+            S[36 * (size_t)id + t] = out;
         }
     } else {
         const uint32_t f = id - n_blocks;
@@ -1729,13 +1744,15 @@ __global__ __launch_bounds__(256) void packed_scatter_kernel(const PackedSeg* __
 {
     const PackedSeg sg = table[blockIdx.x];
     const bool fill = sg.src_offset == ~0ull;
-    const uint4* src = reinterpret_cast<const uint4*>(payload + (fill ? 0 : sg.src_offset));
+    // (payload == nullptr: src_offset is the source's address itself - device arrays gathered into pinned host memory)
+    const unsigned char* const sbytes = payload ? payload + (fill ? 0 : sg.src_offset) : reinterpret_cast<const unsigned char*>(fill ? 0 : sg.src_offset);
+    const uint4* src = reinterpret_cast<const uint4*>(sbytes);
     uint4* dst = reinterpret_cast<uint4*>(sg.dst);
     const uint64_t units = sg.bytes / 16;
     for (uint64_t u = blockIdx.y * 256u + threadIdx.x; u < units; u += kPackSlices * 256u) dst[u] = fill ? uint4{0u, 0u, 0u, 0u} : src[u];
     if (blockIdx.y == 0 && threadIdx.x < (sg.bytes & 15)) {
         const uint64_t b = units * 16 + threadIdx.x;
-        reinterpret_cast<unsigned char*>(sg.dst)[b] = fill ? (unsigned char)0 : (payload + sg.src_offset)[b];
+        reinterpret_cast<unsigned char*>(sg.dst)[b] = fill ? (unsigned char)0 : sbytes[b];
     }
 }
 
@@ -1833,7 +1850,7 @@ __global__ __launch_bounds__(256) void ba_ls_candidate_kernel(uint32_t n_cam, ui
                                                               const double* __restrict__ pts, const double* __restrict__ dc_full,
                                                               const double* __restrict__ dp, const double a, const double lo, const double hi,
                                                               double* __restrict__ cams_out, double* __restrict__ pts_out,
-                                                              double* __restrict__ ls_part)
+                                                              double* __restrict__ ls_part, double* __restrict__ campre_c)
 {
     __shared__ double red[8];
     double st2 = 0.0, dmax = 0.0;
@@ -1850,8 +1867,15 @@ __global__ __launch_bounds__(256) void ba_ls_candidate_kernel(uint32_t n_cam, ui
     } else {
         for (uint32_t i = threadIdx.x; i < n_cam * 6; i += 256) {
             const double d = dc_full[i];
-            cams_out[i] = cams[i] + a * d;
+            cams_out[i] = fma(a, d, cams[i]);   // (spelled out: the pose table below must be that of exactly these values)
             dmax = fmax(dmax, fabs(d));
+        }
+        // the trial's pose table (what a ba_pose_prepare launch did): a lane per camera, from the same sums
+        for (uint32_t c = threadIdx.x; c < n_cam; c += 256) {
+            double cc[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cc[k] = fma(a, dc_full[6 * (size_t)c + k], cams[6 * (size_t)c + k]);
+            pose_prepare(cc, campre_c + kPoseStride * (size_t)c);
         }
     }
     st2 = wave_sum(st2); dmax = wave_max(dmax);
@@ -1933,10 +1957,11 @@ __global__ __launch_bounds__(1024) void ba_ls_sums_kernel(const double* __restri
 }
 
 void launch_ls_candidate(hipStream_t s, uint32_t n_cam, uint32_t n_pt, const double* cams, const double* pts, const double* dc_full,
-                         const double* dp, double a, double bound_lo, double bound_hi, double* cams_out, double* pts_out, double* ls_part)
+                         const double* dp, double a, double bound_lo, double bound_hi, double* cams_out, double* pts_out, double* ls_part,
+                         double* campre_c)
 {
     hipLaunchKernelGGL(ba_ls_candidate_kernel, dim3(ls_candidate_blocks(n_pt)), dim3(256), 0, s, n_cam, n_pt, cams, pts, dc_full, dp, a,
-                       bound_lo, bound_hi, cams_out, pts_out, ls_part);
+                       bound_lo, bound_hi, cams_out, pts_out, ls_part, campre_c);
 }
 
 void launch_ls_eval(hipStream_t s, uint32_t n_tiles, const Tile* tiles, const float4* uv, const uint32_t* obs_pt, const double* campre_c,
@@ -2004,14 +2029,15 @@ void launch_schur_reduce(hipStream_t s, uint32_t n_blocks, uint32_t n_free, cons
                          const uint32_t* cam_ptr, const uint32_t* cam_off, const uint32_t* blk_row, const uint32_t* blk_col,
                          const uint32_t* free_cam, const double* campre, const double* slab, const uint32_t* cam_tile_start,
                          const double* tile_part, double* S, double* rhs, double* diagB, double* gc_red, const double* cost_in,
-                         double* cost_out)
+                         double* cost_out, const CamDamp* damp)
 {
     if (!(n_blocks + n_free)) {
         (void)hipMemcpyAsync(cost_out, cost_in, sizeof(double), hipMemcpyDeviceToDevice, s);
         return;
     }
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(n_blocks + n_free), dim3(64), 0, s, n_blocks, n_free, blk_ptr, blk_off, cam_ptr,
-                       cam_off, blk_row, blk_col, free_cam, campre, slab, cam_tile_start, tile_part, S, rhs, diagB, gc_red, cost_in, cost_out);
+                       cam_off, blk_row, blk_col, free_cam, campre, slab, cam_tile_start, tile_part, S, rhs, diagB, gc_red, cost_in, cost_out,
+                       damp ? *damp : CamDamp{}, damp ? 1 : 0);
 }
 
 void launch_cam_damp(hipStream_t s, uint32_t n_free, const double* diagB, double* sc, int init_scale, int jacobi,

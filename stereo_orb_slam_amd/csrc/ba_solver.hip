@@ -147,8 +147,9 @@ struct soslam_ba {
     double* host_scal = nullptr;        // host_raw + 4
     unsigned long long* host_seq = nullptr;   // behind host_raw: sequence number of the last publication
     unsigned long long publish_seq = 0;
-    unsigned char* up_host[2] = {nullptr, nullptr};   // pinned staging of the packed uploads (PackedSeg table, then payloads): the index
-    size_t up_host_bytes[2] = {0, 0};                 // arrays, and - their kernel may still be reading - the table of the fills
+    unsigned char* up_host[3] = {nullptr, nullptr, nullptr};   // pinned staging of the packed transfers (PackedSeg table, then payloads):
+    size_t up_host_bytes[3] = {0, 0, 0};                       // the index arrays; the table of the fills (the first kernel may still be
+                                                               // reading); the state, in and out (set_state / get_state)
     double* ps_host = nullptr;          // pinned: record (PSV_COUNT) + sequence word + iteration log of the resident structure-only solve
     int ps_host_entries = 0;
     DevBuf<double> ps_log;              // the same log on the device while the kernel runs
@@ -1191,6 +1192,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
         SOSLAM_HIP_CHECK(hipGetLastError());
         return wait_host_seq(h, h->host_seq, published);
     }
+    bool damp_fused = false;
     {
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
         run_schur(h, lm);
@@ -1201,9 +1203,13 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
             h->fac_pending = false;
             h->fac_idx ^= 1;
         }
+        // one rank and a dense solve (the reference's sliding windows): the camera damping rides along - the diagonal of B is
+        // this rank's, complete, and nothing between here and the solve needs S undamped
+        damp_fused = !h->collective() && h->n_free && h->solver == SOSLAM_SOLVER_DENSE_CHOLESKY;
+        const CamDamp fd{h->diagB(), h->sc.p, h->lc.p, h->diag_block.p, lm, h->scale_init ? 0 : 1, h->opt.jacobi_scaling, h->n_free};
         launch_schur_reduce(s, h->n_blocks, h->n_free, h->blk_contrib_ptr.p, h->blk_contrib_off.p, h->cam_contrib_ptr.p,
                             h->cam_contrib_off.p, h->blk_row.p, h->blk_col.p, h->free_cam.p, h->campre.p, h->slab.p, h->cam_tile_start.p, h->tile_part.p,
-                            h->S(), h->rhs(), h->diagB(), h->gc_red(), h->scalp() + SC_COST_X, h->tail());
+                            h->S(), h->rhs(), h->diagB(), h->gc_red(), h->scalp() + SC_COST_X, h->tail(), damp_fused ? &fd : nullptr);
     }
     {
         StageScope sc(h, SOSLAM_STAGE_ALLREDUCE);
@@ -1215,7 +1221,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
         const bool damp_in_gather = h->use_cr && h->n_free && (h->solver == SOSLAM_SOLVER_BAND_CHOLESKY || h->pcg_band) &&
                                     h->solver != SOSLAM_SOLVER_DENSE_CHOLESKY;
         const CamDamp damp{h->diagB(), h->sc.p, h->lc.p, h->diag_block.p, lm, h->scale_init ? 0 : 1, h->opt.jacobi_scaling, h->n_free};
-        if (!damp_in_gather)
+        if (!damp_in_gather && !damp_fused)
             launch_cam_damp(s, h->n_free, h->diagB(), h->sc.p, h->scale_init ? 0 : 1, h->opt.jacobi_scaling, lm, h->diag_block.p,
                             h->S(), h->lc.p);
         h->scale_init = true;
@@ -1593,8 +1599,7 @@ int ls_evaluate(soslam_ba* h, double a)
     SOSLAM_CHECK(h->ls_tile.alloc(2 * (size_t)std::max<uint32_t>(h->n_tiles, 1)));
     SOSLAM_CHECK(h->ls_part.alloc(2 * (size_t)ls_candidate_blocks(h->n_pt)));
     launch_ls_candidate(s, h->n_cam, h->n_pt, h->cams[h->cur].p, h->pts[h->cur].p, h->dc_full.p, h->dp.p, a, h->opt.lower_bound,
-                        h->opt.upper_bound, h->cams[h->cur ^ 1].p, h->pts[h->cur ^ 1].p, h->ls_part.p);
-    launch_pose_prepare(s, h->n_cam, h->cams[h->cur ^ 1].p, h->campre_c.p);
+                        h->opt.upper_bound, h->cams[h->cur ^ 1].p, h->pts[h->cur ^ 1].p, h->ls_part.p, h->campre_c.p);
     launch_ls_eval(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->dc_full.p, h->dp.p, h->cam_free.p,
                    h->proj, h->opt.huber_delta, h->ls_tile.p);
     const unsigned long long seq = ++h->publish_seq;
@@ -1948,6 +1953,23 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
     return SOSLAM_OK;
 }
 
+// pinned staging of the state transfers (region 2): a two-entry table in front, `bytes` of payload behind it
+int state_staging(soslam_ba* h, size_t bytes, double** payload)
+{
+    constexpr size_t kTable = 64;   // two PackedSeg, padded
+    static_assert(2 * sizeof(PackedSeg) <= kTable, "table room");
+    const size_t need = kTable + bytes;
+    if (need > h->up_host_bytes[2]) {
+        if (h->up_host[2]) (void)hipHostFree(h->up_host[2]);
+        h->up_host[2] = nullptr; h->up_host_bytes[2] = 0;
+        const size_t cap = std::max<size_t>(need + need / 4, 1u << 16);
+        SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->up_host[2]), cap, hipHostMallocDefault));
+        h->up_host_bytes[2] = cap;
+    }
+    *payload = reinterpret_cast<double*>(h->up_host[2] + kTable);
+    return SOSLAM_OK;
+}
+
 }  // namespace
 
 // ---- C ABI -------------------------------------------------------------------------------------------
@@ -2082,11 +2104,25 @@ int soslam_ba_set_state(soslam_ba* h, const double* poses, const double* points)
     if (!h || !poses || (h->n_pt && !points)) return SOSLAM_ERR_INVALID_ARGUMENT;
     if (!h->have_problem) { set_last_error("set_state before set_problem"); return SOSLAM_ERR_STATE; }
     SOSLAM_HIP_CHECK(hipSetDevice(h->device));
-    std::vector<double> p((size_t)h->n_pt * 3);
-    for (uint32_t i = 0; i < h->n_pt; i++) std::memcpy(&p[3 * (size_t)i], points + 3 * (size_t)h->pt_int2user[i], 3 * sizeof(double));
     h->cur = 0;
-    SOSLAM_HIP_CHECK(hipMemcpyAsync(h->cams[0].p, poses, sizeof(double) * 6 * h->n_cam, hipMemcpyHostToDevice, h->stream));
-    if (h->n_pt) SOSLAM_HIP_CHECK(hipMemcpyAsync(h->pts[0].p, p.data(), sizeof(double) * p.size(), hipMemcpyHostToDevice, h->stream));
+    const size_t cam_bytes = sizeof(double) * 6 * h->n_cam, pt_bytes = sizeof(double) * 3 * (size_t)h->n_pt;
+    if (cam_bytes + pt_bytes <= kPackedUploadMax && !getenv("SOSLAM_NO_PACKED_UPLOAD")) {
+        // small states: permuted straight into pinned staging, one kernel moves both arrays
+        double* stage = nullptr;
+        SOSLAM_CHECK(state_staging(h, cam_bytes + pt_bytes, &stage));
+        PackedSeg* table = reinterpret_cast<PackedSeg*>(h->up_host[2]);
+        std::memcpy(stage, poses, cam_bytes);
+        double* sp = stage + 6 * (size_t)h->n_cam;
+        for (uint32_t i = 0; i < h->n_pt; i++) std::memcpy(sp + 3 * (size_t)i, points + 3 * (size_t)h->pt_int2user[i], 3 * sizeof(double));
+        table[0] = PackedSeg{h->cams[0].p, 0, cam_bytes};
+        table[1] = PackedSeg{h->pts[0].p, cam_bytes, pt_bytes};
+        launch_packed_scatter(h->stream, table, h->n_pt ? 2 : 1, reinterpret_cast<const unsigned char*>(stage));
+    } else {
+        std::vector<double> p((size_t)h->n_pt * 3);
+        for (uint32_t i = 0; i < h->n_pt; i++) std::memcpy(&p[3 * (size_t)i], points + 3 * (size_t)h->pt_int2user[i], 3 * sizeof(double));
+        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->cams[0].p, poses, cam_bytes, hipMemcpyHostToDevice, h->stream));
+        if (h->n_pt) SOSLAM_HIP_CHECK(hipMemcpyAsync(h->pts[0].p, p.data(), pt_bytes, hipMemcpyHostToDevice, h->stream));
+    }
     SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->last_rel_decrease = 1.0;   // a new starting point: the first solve factors afresh
     h->radius = h->opt.initial_radius;
@@ -2105,6 +2141,22 @@ int soslam_ba_get_state(soslam_ba* h, double* poses, double* points)
     if (!h) return SOSLAM_ERR_INVALID_ARGUMENT;
     if (!h->have_state) { set_last_error("get_state before set_state"); return SOSLAM_ERR_STATE; }
     SOSLAM_HIP_CHECK(hipSetDevice(h->device));
+    const size_t cam_bytes = sizeof(double) * 6 * h->n_cam, pt_bytes = sizeof(double) * 3 * (size_t)h->n_pt;
+    if (cam_bytes + pt_bytes <= kPackedUploadMax && !getenv("SOSLAM_NO_PACKED_UPLOAD")) {
+        // small states: one kernel gathers both arrays into pinned memory
+        double* stage = nullptr;
+        SOSLAM_CHECK(state_staging(h, cam_bytes + pt_bytes, &stage));
+        PackedSeg* table = reinterpret_cast<PackedSeg*>(h->up_host[2]);
+        table[0] = PackedSeg{stage, (uint64_t)reinterpret_cast<uintptr_t>(h->cams[h->cur].p), cam_bytes};
+        table[1] = PackedSeg{stage + 6 * (size_t)h->n_cam, (uint64_t)reinterpret_cast<uintptr_t>(h->pts[h->cur].p), pt_bytes};
+        launch_packed_scatter(h->stream, table, h->n_pt ? 2 : 1, nullptr);
+        SOSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (poses) std::memcpy(poses, stage, cam_bytes);
+        const double* sp = stage + 6 * (size_t)h->n_cam;
+        if (points)
+            for (uint32_t i = 0; i < h->n_pt; i++) std::memcpy(points + 3 * (size_t)h->pt_int2user[i], sp + 3 * (size_t)i, 3 * sizeof(double));
+        return SOSLAM_OK;
+    }
     std::vector<double> c((size_t)h->n_cam * 6), p((size_t)h->n_pt * 3);
     SOSLAM_HIP_CHECK(hipMemcpyAsync(c.data(), h->cams[h->cur].p, sizeof(double) * c.size(), hipMemcpyDeviceToHost, h->stream));
     if (h->n_pt) SOSLAM_HIP_CHECK(hipMemcpyAsync(p.data(), h->pts[h->cur].p, sizeof(double) * p.size(), hipMemcpyDeviceToHost, h->stream));
