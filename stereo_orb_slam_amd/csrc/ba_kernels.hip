@@ -1836,6 +1836,12 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ba_schur_kernel<16>), dim3(n_chunks), dim3(schur_threads(16)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
                            q_pt, q_slot, ar.g, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
+    } else if (kmax <= 20) {
+        // the reference's 20-frame sliding windows: 120 window rows = eight tile rows, 36 tiles instead of the 78 of a 32-camera image
+        constexpr size_t lds = SchurShape<20>::lds_bytes;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<20>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ba_schur_kernel<20>), dim3(n_chunks), dim3(schur_threads(20)), lds, s, chunks, batches, chunk_slab, chunk_cam, pt_obs,
+                           q_pt, q_slot, ar.g, campre, pts, C, gp, sp, lm, Cinv, ptfac, slab, scal);
     } else {
         constexpr size_t lds = SchurShape<32>::lds_bytes;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

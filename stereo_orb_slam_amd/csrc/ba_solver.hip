@@ -583,7 +583,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     }
     // window width of the Schur kernel: the narrowest instantiation that holds the longest windowed track (10 cameras =
     // 60 rows fill four 16-row tiles of the matrix cores exactly; 11 would need a fifth tile row: 15 tiles instead of 10)
-    h->kmax = max_track > 16 ? 32 : (max_track > 10 ? 16 : 10);
+    h->kmax = max_track > 20 ? 32 : (max_track > 16 ? 20 : (max_track > 10 ? 16 : 10));
     std::vector<uint32_t> row_first(nf + 1, 0);
     for (uint32_t f = 0; f < nf; f++) row_first[f + 1] = row_first[f] + (uint32_t)rows[f].size();
     h->n_blocks = row_first[nf];

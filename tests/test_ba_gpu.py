@@ -699,10 +699,12 @@ def test_a_kept_handle_gives_the_same_answers(gpu, prob1):
         assert h.solve().iterations == 2
 
 
-def test_long_tracks_use_the_wide_window(gpu, oracle_lib):
-    """Tracks of 24 cameras select the 32-slot Schur window."""
+@pytest.mark.parametrize("track_len", [12, 19, 24])
+def test_long_tracks_use_the_wide_window(gpu, oracle_lib, track_len):
+    """Tracks of 12, 19 and 24 cameras select the 16-, 20- and 32-slot instantiations of the windowed Schur kernel (20: the
+    reference's own sliding windows, slam.cpp:126-129)."""
     ba, synth, L = gpu
-    p = synth.generate_ba(None, n_cam=40, n_pt=1500, track_mode=0, track_len=24, spacing=0.3)
+    p = synth.generate_ba(None, n_cam=40, n_pt=1500, track_mode=0, track_len=track_len, spacing=0.3)
     ref = oracle_lib.step(p.obs_cam, p.obs_pt, p.obs_uv, p.poses_cw(), p.points_f64(), p.proj_l, p.proj_r, p.cam_fixed, 1e4)
     with ba.BundleAdjustment(ba.default_options(linear_solver=1)) as h:
         h.load(p)
