@@ -168,9 +168,16 @@ constexpr int kCrInvertThreads = 256;
 //     everybody.  A symmetric pair of entries comes out of the same two products rounded the same way in both groups, so
 //     the inverse is bitwise symmetric - the sweep relies on it (rows taken from differently rounded inverses were
 //     measured to cost four digits of the factor).
-template <int NSTEPS>
-__device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4][64], double (*pblk)[16], const int wave, const int lane)
+// NT: tile rows = tile columns = waves of the workgroup (4: the 64 x 64 image).  NT = 8 - a 128 x 128 image on eight waves - was built
+// and measured as a one-sweep replacement of dense2_solve's two-block elimination at 19 cameras: 51 us against 43.  Two waves share
+// each SIMD's f64 and matrix pipes, a step carries four times the matrix work of a 64-row step (eight tiles per wave, two waves), and
+// 38 such steps are more than 2 x 20 small ones plus the two block products.  The template parameter stays for what it is worth to a
+// cyclic reduction with super-blocks wider than ten cameras.
+template <int NSTEPS, int NT = 4>
+__device__ __forceinline__ bool gj_sweep(double4_t (&acc)[NT], double (*strips)[4][16 * NT], double (*pblk)[16], const int wave, const int lane)
 {
+    constexpr int W = 16 * NT;                          // image width = strip length
+    static_assert(3 * NSTEPS <= W, "pivot rows inside the image");
     const int lr = lane % 16, lk = lane / 16;
     const int g = lk < 3 ? lk : 0;                       // the padding group computes group 0's row and multiplies zeros with it
     const int p0 = g, p1 = (g + 1) % 3, p2 = (g + 2) % 3;
@@ -179,11 +186,12 @@ __device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4
     const int u01 = (p0 < p1 ? p0 : p1) * 3 + (p0 < p1 ? p1 : p0), u02 = (p0 < p2 ? p0 : p2) * 3 + (p0 < p2 ? p2 : p0),
               u12 = (p1 < p2 ? p1 : p2) * 3 + (p1 < p2 ? p2 : p1);
     // strip rows this lane reads: its B operand row (zeros for the padding k = 3) and the three pivot rows in permuted order
-    const int zb = (lk < 3 ? lk : 3) * 64 + 16 * wave + lr;
-    const int za0 = (lk < 3 ? p0 : 3) * 64 + lr, za1 = (lk < 3 ? p1 : 3) * 64 + lr, za2 = (lk < 3 ? p2 : 3) * 64 + lr;
+    const int zb = (lk < 3 ? lk : 3) * W + 16 * wave + lr;
+    const int za0 = (lk < 3 ? p0 : 3) * W + lr, za1 = (lk < 3 ? p1 : 3) * W + lr, za2 = (lk < 3 ? p2 : 3) * W + lr;
     const int jcol = 16 * wave + lr;                     // the column this lane holds
-    if (threadIdx.x < 128) strips[threadIdx.x / 64][3][threadIdx.x % 64] = 0.0;
+    if (threadIdx.x < 2 * W) strips[threadIdx.x / W][3][threadIdx.x % W] = 0.0;   // (64 NT lanes in the workgroup: >= 2 W)
     bool ok = true;
+    int bad = 0;   // NT = 8: see the pivot test below
     // publish the pivot rows of step kb (static), then zero them.  Rows that sit in the same accumulator register (two steps
     // in four all three do) go out with one store: lane group lk holds row k0 + (lk - k0 % 4).
     auto publish = [&](const int kb) __attribute__((always_inline)) {
@@ -201,7 +209,7 @@ __device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4
                     pb[c * 3 + cj] = val;
                     val = cj == c ? 1.0 : 0.0;
                 }
-                strip[c * 64 + jcol] = val;
+                strip[c * W + jcol] = val;
                 acc[qa / 4][qa % 4] = 0.0;
             }
         }
@@ -213,13 +221,16 @@ __device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4
                     pb[c * 3 + cj] = val;
                     val = cj == c ? 1.0 : 0.0;
                 }
-                strip[c * 64 + jcol] = val;
+                strip[c * W + jcol] = val;
                 acc[qb / 4][qb % 4] = 0.0;
             }
         }
     };
     publish(0);
-    double aop_t[4] = {0.0, 0.0, 0.0, 0.0}, sv_t = 0.0;   // operands of the updates the previous step left for this one
+    double aop_t[NT], sv_t = 0.0;   // operands of the updates the previous step left for this one
+#pragma unroll
+    for (int tr = 0; tr < NT; tr++) aop_t[tr] = 0.0;
+    //   // operands of the updates the previous step left for this one
 #pragma unroll
     for (int kb = 0; kb < NSTEPS; kb++) {   // straight-line code: every register index below is static
         const int k0 = 3 * kb;
@@ -228,16 +239,21 @@ __device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4
         __syncthreads();
         // requests first, arithmetic behind them
         const double a = pb[p0 * 4], b = pb[u01], c = pb[u02], d = pb[p1 * 4], e = pb[u12], f = pb[p2 * 4];
-        double ac[4][3];
+        const bool more = kb + 1 < NSTEPS;
+        const int n0 = more ? (k0 + 3) / 16 : -1, n1 = more ? (k0 + 5) / 16 : -1;   // static: the tile rows of the next pivot rows
+        // the pivot rows' entries this lane's A operands need.  Eight tile rows (NT = 8): only those of the tiles updated before
+        // the exchange are requested up front, the rest behind it (48 registers of requests in flight would spill)
+        double ac[NT][3];
 #pragma unroll
-        for (int tr = 0; tr < 4; tr++) { ac[tr][0] = strip[za0 + 16 * tr]; ac[tr][1] = strip[za1 + 16 * tr]; ac[tr][2] = strip[za2 + 16 * tr]; }
+        for (int tr = 0; tr < NT; tr++)
+            if (NT <= 4 || !more || tr == n0 || tr == n1) { ac[tr][0] = strip[za0 + 16 * tr]; ac[tr][1] = strip[za1 + 16 * tr]; ac[tr][2] = strip[za2 + 16 * tr]; }
         const double sv = strip[zb];
         // the previous step's updates of the tiles that did not hold this step's pivot rows: their matrix instructions run
         // while the requests above are under way
         if (kb > 0) {
             const int m0 = k0 / 16, m1 = (k0 + 2) / 16;   // the tile rows the previous step updated before its exchange
 #pragma unroll
-            for (int tr = 0; tr < 4; tr++)
+            for (int tr = 0; tr < NT; tr++)
                 if (tr != m0 && tr != m1) acc[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop_t[tr], sv_t, acc[tr], 0, 0, 0);
         }
         // row 0 of the inverse of the permuted block = row lk of Pinv in the column order p0 p1 p2
@@ -245,7 +261,14 @@ __device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4
         const double det_own = __builtin_fma(a, c00, __builtin_fma(b, c01, c * c02));
         const double det = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(det_own)),
                                             __builtin_amdgcn_readfirstlane(__double2loint(det_own)));
-        ok = ok && (a > 0.0) && (c00 > 0.0) && (det > 0.0);
+        if constexpr (NT <= 4) {
+            ok = ok && (a > 0.0) && (c00 > 0.0) && (det > 0.0);
+        } else {
+            // the same test, pinned to its step: left to itself the compiler sinks all 3 NSTEPS comparisons behind the last step and
+            // keeps their operands alive until then - 228 registers at 38 steps, the whole budget of a wave of eight
+            const int fail = (a > 0.0) && (c00 > 0.0) && (det > 0.0) ? 0 : 1;
+            asm volatile("v_or_b32 %0, %0, %1" : "+v"(bad) : "v"(fail));
+        }
         double id = __builtin_amdgcn_rcp(det);
         id = id * (2.0 - det * id);
         id = id * (2.0 - det * id);
@@ -257,13 +280,11 @@ __device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4
             const double v = ac[tr][0] * r0 + ac[tr][1] * r1 + ac[tr][2] * r2;
             return 16 * tr + lr < k0 + 3 ? v : -v;
         };
-        const bool more = kb + 1 < NSTEPS;
-        const int n0 = more ? (k0 + 3) / 16 : -1, n1 = more ? (k0 + 5) / 16 : -1;   // static: the tile rows of the next pivot rows
         // pivot columns start from zero: only the wave(s) that hold them (a scalar branch), the lanes under the execution mask
         if (wave == k0 / 16 || wave == (k0 + 2) / 16) {
             if (pcol) {
 #pragma unroll
-                for (int tr = 0; tr < 4; tr++)
+                for (int tr = 0; tr < NT; tr++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) asm volatile("v_mov_b64 %0, 0" : "=v"(acc[tr][r]));
             }
@@ -273,17 +294,20 @@ __device__ __forceinline__ bool gj_sweep(double4_t (&acc)[4], double (*strips)[4
             acc[n0] = __builtin_amdgcn_mfma_f64_16x16x4f64(operand(n0), sv, acc[n0], 0, 0, 0);
             if (n1 != n0) acc[n1] = __builtin_amdgcn_mfma_f64_16x16x4f64(operand(n1), sv, acc[n1], 0, 0, 0);
 #pragma unroll
-            for (int tr = 0; tr < 4; tr++)
-                if (tr != n0 && tr != n1) aop_t[tr] = operand(tr);
+            for (int tr = 0; tr < NT; tr++)
+                if (tr != n0 && tr != n1) {
+                    if (NT > 4) { ac[tr][0] = strip[za0 + 16 * tr]; ac[tr][1] = strip[za1 + 16 * tr]; ac[tr][2] = strip[za2 + 16 * tr]; }
+                    aop_t[tr] = operand(tr);
+                }
             sv_t = sv;
             __builtin_amdgcn_sched_barrier(0);   // the operands above fill the wait for the matrix instruction's result
             publish(kb + 1);
         } else {
 #pragma unroll
-            for (int tr = 0; tr < 4; tr++) acc[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(operand(tr), sv, acc[tr], 0, 0, 0);
+            for (int tr = 0; tr < NT; tr++) acc[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(operand(tr), sv, acc[tr], 0, 0, 0);
         }
     }
-    return ok;
+    return ok && bad == 0;
 }
 
 
@@ -1450,21 +1474,5 @@ void launch_dense_spd_inverse60(hipStream_t s, double* A, int nb, double* ebuf, 
 }
 
 bool dense2_fits(uint32_t n_rows) { return n_rows >= 1 && n_rows <= 2 * (uint32_t)kDense2Cams; }
-
-void launch_dense2_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, const double* b,
-                         double* x, double* scal)
-{
-    if (!A.n_rows) return;
-    const size_t lds = sizeof(double) * 4 * 64 * kLd;
-    static bool attr_set[64] = {};     // per device: the attribute belongs to the function on that device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev = dev >= 0 && dev < 64 ? dev : 0;
-    if (!attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense2_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(dense2_solve_kernel, dim3(1), dim3(kDense2Threads), lds, s, A, n_blocks, blk_row, blk_col, b, x, scal);
-}
 
 }  // namespace soslam
