@@ -1939,8 +1939,12 @@ int run_lm(soslam_ba* h, int fixed_count, soslam_ba_summary* out)
     sum.iterations = it;
     sum.final_cost = h->x_cost;
     if (!have_initial) {
-        // zero iterations requested: report the cost of the current point
-        if (!h->x_cost_known) {
+        // zero iterations requested (or the clock ran out before the first): report the cost of the current point
+        if (!h->x_cost_known && points_only(h)) {
+            // the structure-only path has no linearisation of its own: one step kernel, of which only the cost at x is kept
+            SOSLAM_CHECK(take_step(h, h->radius));
+            h->x_cost = h->host_raw[0];
+        } else if (!h->x_cost_known) {
             SOSLAM_HIP_CHECK(hipMemcpyAsync(h->host_scal, h->scalp(), sizeof(double), hipMemcpyDeviceToHost, s));
             SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
             h->x_cost = h->host_scal[0];

@@ -1475,4 +1475,20 @@ void launch_dense_spd_inverse60(hipStream_t s, double* A, int nb, double* ebuf, 
 
 bool dense2_fits(uint32_t n_rows) { return n_rows >= 1 && n_rows <= 2 * (uint32_t)kDense2Cams; }
 
+void launch_dense2_solve(hipStream_t s, const BsrView& A, uint32_t n_blocks, const uint32_t* blk_row, const uint32_t* blk_col, const double* b,
+                         double* x, double* scal)
+{
+    if (!A.n_rows) return;
+    const size_t lds = sizeof(double) * 4 * 64 * kLd;
+    static bool attr_set[64] = {};     // per device: the attribute belongs to the function on that device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev >= 0 && dev < 64 ? dev : 0;
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense2_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(dense2_solve_kernel, dim3(1), dim3(kDense2Threads), lds, s, A, n_blocks, blk_row, blk_col, b, x, scal);
+}
+
 }  // namespace soslam

@@ -299,6 +299,26 @@ def test_structure_only_solve_resident_on_the_device_matches_the_oracle(gpu, ora
     np.testing.assert_allclose([e.radius for e in logs[0]], [e.radius for e in logs[1]], rtol=1e-8)
 
 
+def test_wall_clock_limit_ends_a_solve_on_every_path(gpu, prob1):
+    """/root/reference/src/params.h:41 (BA_MAX_SOLVER_TIME through bundle_adjuster.cpp:18): Ceres tests the clock at the top of an
+    iteration.  The host loop reads the host's clock; the resident structure-only solve has no host in its loop - every workgroup
+    reads the device's constant clock, the votes travel with the pass's sums and all workgroups leave together."""
+    ba, synth, L = gpu
+    frame = synth.generate_ba(None, n_cam=1, n_pt=1000, track_mode=0, track_len=1)
+    for p, kw in ((frame, {}), (frame, dict(profile_stages=1)), (prob1, {})):
+        with ba.BundleAdjustment(ba.default_options(max_iterations=50, max_solver_time_seconds=1e-7, function_tolerance=0.0,
+                                                    parameter_tolerance=0.0, gradient_tolerance=0.0, **kw)) as h:
+            h.load(p)
+            s = ba.summary_dict(h.solve())
+            # (the host's clock has run out before the first iteration - Ceres evaluates the starting point and stops; a device
+            # clock's vote is known with the first pass's sums)
+            assert "time" in s["termination_name"].lower() and s["iterations"] <= 2 and s["initial_cost"] > 0.0, s
+            assert s["final_cost"] <= s["initial_cost"]
+            h.set_options(ba.default_options(max_iterations=50, max_solver_time_seconds=30.0))
+            s2 = ba.summary_dict(h.solve())
+            assert "time" not in s2["termination_name"].lower() and s2["final_cost"] < s["final_cost"], s2
+
+
 def test_observation_order_invariance(gpu, prob1):
     """The solver sorts observations itself (camera-major, point-major): a shuffled input gives the same
     reduced system to rounding and the same solution."""
