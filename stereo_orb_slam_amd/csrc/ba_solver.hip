@@ -972,7 +972,13 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     // 20); six rigid-body modes per aggregate of consecutive free cameras span them.
     h->two_level = h->solver == SOSLAM_SOLVER_PCG && !h->pcg_band && nf >= kPcgMultiMinRows && std::getenv("SOSLAM_NO_TWO_LEVEL") == nullptr;
     if (h->two_level) {
-        const uint32_t per = std::max<uint32_t>(12, (nf + 199) / 200);   // cameras per aggregate: at most 200 aggregates (1 200 coarse unknowns)
+        // cameras per aggregate: at most 200 aggregates (1 200 coarse unknowns).  Measured on configs[2] with 10 % of tracks of length 20
+        // (scripts/tl_agg_probe.py): aggregates of 12 / 6 / 4 cameras take 68 / 53 / 46 PCG iterations per solve, 2.84 / 2.50 / 2.46 ms per
+        // LM iteration - the coarse inverse grows as fast as the iterations shrink.  (Letting that inverse lag one solve behind, as
+        // the pose graph does, is NOT an option here: the damping on S changes threefold from one iteration to the next, and a
+        // coarse operator of the previous matrix sent the PCG to 400 - 1 300 iterations.)
+        uint32_t per = std::max<uint32_t>(6, (nf + 199) / 200);
+        if (const char* e = std::getenv("SOSLAM_TL_AGG")) per = std::max<uint32_t>((uint32_t)std::max(1, std::atoi(e)), (nf + 199) / 200);   // development
         if (per > 42) h->two_level = false;                              // one workgroup of pcg2 per aggregate: 42 block rows
         else {
             std::vector<uint32_t> agg_ptr{0}, row_agg(nf), agg_ref;
