@@ -104,7 +104,11 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
             if (h->h_free[ef[k]] >= 0 && h->h_free[et[k]] >= 0) { adj[ef[k]].push_back(et[k]); adj[et[k]].push_back(ef[k]); }
         // aggregate sizes: as even as the cap allows (a count of ceil(nf / kAggMax) aggregates, sizes within one of each other
         // would need a partitioner; breadth-first growth to the target size, leftovers joined to a neighbouring aggregate or kept)
-        const uint32_t target = 34;        // growth stops here; what is left between grown aggregates is merged into them up to kAggMax
+        // growth stops here; what is left between grown aggregates is merged into them up to kAggMax.  configs[4], ten iterations
+        // (scripts/pg_agg_probe.py): targets 28 / 30 / 32 / 34 / 38 / 40 / 42 give 29.0 / 28.2 / 28.7 / 30.6 / 28.4 / 27.7 / 31.5 ms - a noisy
+        // function of where the cuts fall, flat between 28 and 40
+        uint32_t target = 30;
+        if (const char* e = std::getenv("SOSLAM_PG_AGG")) target = (uint32_t)std::min(std::max(std::atoi(e), 4), (int)kAggMax);   // development
         std::vector<int32_t> agg_of(n_vertex, -1);
         std::vector<std::vector<uint32_t>> members;
         std::vector<uint32_t> queue;
@@ -162,6 +166,9 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
         h->n_agg = (uint32_t)agg_ptr.size() - 1;
         h->last_lin_it = 0;
         h->ncp = (h->n_agg * 6 + 59) / 60 * 60;
+        // the coarse kernels hold P^T r of every aggregate in LDS (1 260 entries): a graph that breaks into more pieces than that
+        // (many small components) keeps the aggregate numbering and takes block-Jacobi
+        if (h->ncp > 1260) { h->two_level = false; h->n_agg = 0; h->ncp = 0; }
     } else {
         h->n_agg = 0; h->ncp = 0;
     }
