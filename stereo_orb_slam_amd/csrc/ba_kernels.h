@@ -158,6 +158,23 @@ void launch_schur(hipStream_t s, int kmax, uint32_t n_chunks, const SchurChunk* 
 // into +inf before the scalars are summed, so every rank sees a non-finite candidate and rejects the step alike.
 void launch_status_poison(hipStream_t s, double* scal);
 
+// Small problems (at most 32 cameras - the reference's windows): ba_cam_update + ba_backsub + ba_cost in ONE launch.  Every workgroup
+// forms the candidate cameras and their pose table itself; cost_part gets backsub_blocks(n_pt) entries (one per workgroup).
+// sums != NULL: the workgroup that finishes last also sums the step scalars, tests acceptance and publishes (what launch_step_sums
+// does in a launch of its own; same arguments); arrivals: one zero-initialised word the kernel leaves zero
+struct StepSumsLaunch {
+    double* out5; double* out_cam5; double* out_cost; double* gate; const double* status;
+    double x_cost, min_relative_decrease; int gate_enabled; double stop_vote;
+    double* pub_src; int n_pub, clear_first, clear_n; double* host_dst; unsigned long long* host_seq; unsigned long long seq; int armijo_in_gate;
+};
+bool apply_small_fits(uint32_t n_cam, uint32_t n_pt);
+void launch_apply_small(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams, const double* dc_free, const double* lc,
+                        const double* gc_red, const double* lin_resid, double* cams_out, double* dc_full, double* dcw, double* cam_part,
+                        double* campre_c, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam, const double* ar,
+                        const double* campre, const double* Cinv, const double* C, const double* gp, const double* sp, const double* pts, LmDiag lm,
+                        double bound_lo, double bound_hi, double* pts_out, double* dp, double* part, const float4* uv, const Proj& P, double delta,
+                        double* cost_part, unsigned int* arrivals, const StepSumsLaunch* sums);
+
 // ---- small problems' uploads in one command ------------------------------------------------------------------------------
 // The index of a window of a few thousand observations is ~35 arrays of a few KB: as separate copy commands they cost more than
 // the index takes to build.  The host packs them into one pinned buffer (table of segments, then the 16-byte aligned payloads)

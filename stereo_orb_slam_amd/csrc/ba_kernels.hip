@@ -323,27 +323,37 @@ __global__ __launch_bounds__(1024) void sum5_kernel(const double* __restrict__ i
 
 // The two one-workgroup sums that end an iteration in one launch: the back-substitution's five step scalars (as
 // sum5_kernel) and the candidate cost (as sum_strided_kernel, stride 1, scale 0.5), then the optional publication.
-__global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __restrict__ part5, uint32_t n5, double* __restrict__ out5,
-                                                             const double* __restrict__ cam5, uint32_t n_cam5, double* __restrict__ out_cam5,
-                                                             const double* __restrict__ cost_part, uint32_t n_cost,
-                                                             double* __restrict__ out_cost, const StepGate sg, const double stop_vote,
-                                                             const Publish pb)
+// The sums behind a step - the back-substitution's and the camera update's step scalars, the candidate cost -, the acceptance test
+// and the publication, for NT lanes.  SC1: the partials were written by other workgroups of the SAME launch (ba_apply_small's
+// last workgroup runs this): every load of them is an sc1 load.
+struct StepSumsArgs {
+    const double* part5; uint32_t n5; double* out5;
+    const double* cam5; uint32_t n_cam5; double* out_cam5;
+    const double* cost_part; uint32_t n_cost; double* out_cost;
+    StepGate sg; double stop_vote; Publish pb;
+};
+
+template <int NT, bool SC1>
+__device__ __forceinline__ void step_sums_body(const StepSumsArgs& q, double* red /* [NT / 64][11] */, double* fin /* [11] */)
 {
-    __shared__ double red[16 * 11];
-    __shared__ double fin[11];
+    auto ld = [](const double* ptr) __attribute__((always_inline)) -> double {
+        if constexpr (SC1) return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *ptr;
+    };
+    constexpr int NW = NT / kWave;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, mx = 0.0, sc = 0.0;
     double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, cx = 0.0;
-    for (uint32_t i = threadIdx.x; i < n5; i += 1024) {
-        const double* v = part5 + 5 * (size_t)i;
-        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
-        mx = fmax(mx, v[4]);
+    for (uint32_t i = threadIdx.x; i < q.n5; i += NT) {
+        const double* v = q.part5 + 5 * (size_t)i;
+        s0 += ld(v); s1 += ld(v + 1); s2 += ld(v + 2); s3 += ld(v + 3);
+        mx = fmax(mx, ld(v + 4));
     }
-    for (uint32_t i = threadIdx.x; i < n_cam5; i += 1024) {
-        const double* v = cam5 + 5 * (size_t)i;
-        c0 += v[0]; c1 += v[1]; c2 += v[2]; c3 += v[3];
-        cx = fmax(cx, v[4]);
+    for (uint32_t i = threadIdx.x; i < q.n_cam5; i += NT) {
+        const double* v = q.cam5 + 5 * (size_t)i;
+        c0 += ld(v); c1 += ld(v + 1); c2 += ld(v + 2); c3 += ld(v + 3);
+        cx = fmax(cx, ld(v + 4));
     }
-    for (uint32_t i = threadIdx.x; i < n_cost; i += 1024) sc += cost_part[i];
+    for (uint32_t i = threadIdx.x; i < q.n_cost; i += NT) sc += ld(q.cost_part + i);
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); mx = wave_max(mx); sc = wave_sum(sc);
     c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); c3 = wave_sum(c3); cx = wave_max(cx);
     if (threadIdx.x % kWave == 0) {
@@ -353,31 +363,38 @@ __global__ __launch_bounds__(1024) void ba_step_sums_kernel(const double* __rest
     }
     __syncthreads();
     if (threadIdx.x < 11) {
-        // lane k adds (or maximises) value k of the sixteen wave partials, in wave order
+        // lane k adds (or maximises) value k of the wave partials, in wave order
         const int k = threadIdx.x;
         const bool is_max = k == 4 || k == 10;
         double a = 0.0;
-        for (int w = 0; w < 16; w++) a = is_max ? fmax(a, red[w * 11 + k]) : a + red[w * 11 + k];
+        for (int w = 0; w < NW; w++) a = is_max ? fmax(a, red[w * 11 + k]) : a + red[w * 11 + k];
         if (k == 5) a *= 0.5;
         fin[k] = a;
-        if (k < 5) out5[k] = a;
-        else if (k == 5) out_cost[0] = a;
-        else out_cam5[k - 6] = a;
-        if (k == 0) out5[5] = stop_vote;   // SC_STOP
+        if (k < 5) q.out5[k] = a;
+        else if (k == 5) q.out_cost[0] = a;
+        else q.out_cam5[k - 6] = a;
+        if (k == 0) q.out5[5] = q.stop_vote;   // SC_STOP
     }
-    if (sg.gate) {
+    if (q.sg.gate) {
         // The LM loop's acceptance test, on the device: the host has already enqueued the linearisation at the candidate
         // behind this kernel, gated by this word, so an accepted step goes on without waiting for the host (which reads
         // the same word and follows it).  Same operands and operations as run_lm.
         __syncthreads();
         if (threadIdx.x == 0) {
             const double mcc = fin[0] + fin[6], cand = fin[5], gdot = fin[3] + fin[9];
-            const bool ok = sg.status[2] == 0.0 && sg.status[3] == 0.0 && isfinite(mcc) && isfinite(cand) && mcc > 0.0 &&
-                            (!sg.armijo || cand <= sg.x_cost + 1e-4 * gdot);
-            *sg.gate = (sg.enabled && ok && (sg.x_cost - cand) / mcc > sg.min_relative_decrease) ? 1.0 : 0.0;
+            const bool ok = q.sg.status[2] == 0.0 && q.sg.status[3] == 0.0 && isfinite(mcc) && isfinite(cand) && mcc > 0.0 &&
+                            (!q.sg.armijo || cand <= q.sg.x_cost + 1e-4 * gdot);
+            *q.sg.gate = (q.sg.enabled && ok && (q.sg.x_cost - cand) / mcc > q.sg.min_relative_decrease) ? 1.0 : 0.0;
         }
     }
-    publish_tail(pb);
+    publish_tail(q.pb);
+}
+
+__global__ __launch_bounds__(1024) void ba_step_sums_kernel(const StepSumsArgs q)
+{
+    __shared__ double red[16 * 11];
+    __shared__ double fin[11];
+    step_sums_body<1024, false>(q, red, fin);
 }
 
 // The acceptance test on scalars that were summed over the ranks after ba_step_sums wrote them, then the publication.
@@ -1779,9 +1796,10 @@ void launch_step_sums(hipStream_t s, const double* part5, uint32_t n5, double* o
                       double min_relative_decrease, int gate_enabled, double stop_vote, double* pub_src, int n_pub, int clear_first,
                       int clear_n, double* host_dst, unsigned long long* host_seq, unsigned long long seq, int armijo_in_gate)
 {
-    hipLaunchKernelGGL(ba_step_sums_kernel, dim3(1), dim3(1024), 0, s, part5, n5, out5, cam5, n_cam5, out_cam5, cost_part, n_cost, out_cost,
-                       StepGate{gate, status, x_cost, min_relative_decrease, gate_enabled, armijo_in_gate}, stop_vote,
-                       Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n});
+    hipLaunchKernelGGL(ba_step_sums_kernel, dim3(1), dim3(1024), 0, s,
+                       StepSumsArgs{part5, n5, out5, cam5, n_cam5, out_cam5, cost_part, n_cost, out_cost,
+                                    StepGate{gate, status, x_cost, min_relative_decrease, gate_enabled, armijo_in_gate}, stop_vote,
+                                    Publish{pub_src, host_dst, host_seq, seq, n_pub, clear_first, clear_n}});
 }
 
 void launch_gate_publish(hipStream_t s, double* scal, double x_cost, double min_relative_decrease, int gate_enabled, double* pub_src,
@@ -2060,6 +2078,209 @@ void launch_cam_update(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, c
 {
     hipLaunchKernelGGL(ba_cam_update_kernel, dim3(cam_update_blocks(n_cam)), dim3(256), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red,
                        lin_resid, campre, cams_out, dc_full, dcw, cam_part, campre_c);
+}
+
+// ---- small problems (the reference's windows: up to 32 cameras): candidate cameras, back-substitution and candidate cost in one launch --
+// ba_cam_update, ba_backsub and ba_cost are 5 + 6 + 5 us of launch-sized kernels at a 20-frame window, each waiting for the one
+// before.  With few cameras every workgroup can form all candidate cameras and their pose table itself (LDS), so the three
+// become one: per point the step (as ba_backsub), the candidate, and - point-major, through the pt_obs index - the candidate's
+// residuals.  Workgroup 0 also writes what the others only use: candidate cameras, dc_full, w, the pose table, and the camera
+// share of the step scalars.  cost_part gets one entry per workgroup (ba_step_sums adds them as it adds ba_cost's tiles).
+constexpr int kApplySmallCams = 32;
+__global__ __launch_bounds__(kPointBlock) void ba_apply_small_kernel(
+    uint32_t n_cam, const int32_t* __restrict__ cam_free, const double* __restrict__ cams, const double* __restrict__ dc_free,
+    const double* __restrict__ lc, const double* __restrict__ gc_red, const double* __restrict__ lin_resid,
+    double* __restrict__ cams_out, double* __restrict__ dc_full, double* __restrict__ dcw_out, double* __restrict__ cam_part,
+    double* __restrict__ campre_c,
+    uint32_t n_pt, const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_obs, const uint32_t* __restrict__ q_cam,
+    const double* __restrict__ ar, const double* __restrict__ campre, const double* __restrict__ Cinv, const double* __restrict__ C,
+    const double* __restrict__ gp, const double* __restrict__ sp, const double* __restrict__ pts, const LmDiag lm,
+    const double bound_lo, const double bound_hi, double* __restrict__ pts_out, double* __restrict__ dp_out, double* __restrict__ part,
+    const float4* __restrict__ uv, const Proj P, const double delta, double* __restrict__ cost_part,
+    unsigned int* __restrict__ arrivals, const StepSumsArgs sums, const int with_sums)
+{
+    __shared__ double red[(kPointBlock / kWave) * 11];
+    __shared__ double fin[11];
+    __shared__ int s_last;
+    // with_sums: the workgroup that finishes last also does what ba_step_sums does in a launch of its own.  Every partial then
+    // leaves as a write-through (sc1) store of lane 0, which drains them and adds to the arrival counter (MI355X_MICROARCH.md,
+    // "Valid forms", row 1); the last workgroup reads them with sc1 loads
+    auto put = [&](double* ptr, double val) __attribute__((always_inline)) {
+        if (with_sums) __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *ptr = val;
+    };
+    __shared__ double s_x[kApplySmallCams * 6], s_w[kApplySmallCams * 6];
+    __shared__ double s_pre[kApplySmallCams * kPoseStride];
+    const int tid = threadIdx.x;
+    const bool first = blockIdx.x == 0;
+    // ---- the cameras (every workgroup; workgroup 0 publishes) ----
+    {
+        double mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0;
+        const uint32_t c = (uint32_t)tid / 6, a = (uint32_t)tid % 6;
+        if (tid < (int)(n_cam * 6)) {
+            const int32_t f = cam_free[c];
+            const double x = cams[tid];
+            double d = 0.0;
+            if (f >= 0) {
+                const uint32_t fi = 6 * (uint32_t)f + a;
+                d = dc_free[fi];
+                const double g = gc_red[fi];
+                mcc += 0.5 * (lc[fi] * d * d - g * d);
+                if (lin_resid) mcc += 0.5 * d * lin_resid[fi];
+                gd += g * d;
+                x2 += x * x;
+                gm = fmax(gm, fabs(g));
+            }
+            const double xn = x + d;
+            const double e = xn - x;
+            st2 += e * e;
+            s_x[tid] = xn;
+            double wv = d;   // w = M dc_rot (rotation part of J_c dc is A (w x v)) | dc_t
+            if (a < 3) {
+                wv = 0.0;
+                if (f >= 0) {
+                    const double* M = campre + kPoseStride * (size_t)c + 9 + a * 3;
+                    const double* dr = dc_free + 6 * (size_t)f;
+                    wv = M[0] * dr[0] + M[1] * dr[1] + M[2] * dr[2];
+                }
+            }
+            s_w[tid] = wv;
+            if (first) { cams_out[tid] = xn; dc_full[tid] = d; dcw_out[tid] = wv; }
+        }
+        if (first) {
+            mcc = wave_sum(mcc); st2 = wave_sum(st2); x2 = wave_sum(x2); gd = wave_sum(gd); gm = wave_max(gm);
+            if (tid % kWave == 0) {
+                double* o = red + (tid / kWave) * 6;
+                o[0] = mcc; o[1] = st2; o[2] = x2; o[3] = gd; o[4] = gm;
+            }
+        }
+        __syncthreads();
+        if (first && tid == 0) {
+            double a0 = 0, b0 = 0, c0 = 0, d0 = 0, e0 = 0;
+            for (int w = 0; w < kPointBlock / kWave; w++) { a0 += red[w * 6]; b0 += red[w * 6 + 1]; c0 += red[w * 6 + 2]; d0 += red[w * 6 + 3]; e0 = fmax(e0, red[w * 6 + 4]); }
+            put(cam_part, a0); put(cam_part + 1, b0); put(cam_part + 2, c0); put(cam_part + 3, d0); put(cam_part + 4, e0);
+        }
+        if (tid < (int)n_cam) {
+            pose_prepare(s_x + 6 * tid, s_pre + kPoseStride * tid);
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < kPoseStride; i++) campre_c[kPoseStride * (size_t)tid + i] = s_pre[kPoseStride * tid + i];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the points: step (ba_backsub), candidate, the candidate's cost ----
+    const uint32_t p = (blockIdx.x * kPointBlock + (uint32_t)tid) / kBacksubLanes;
+    const uint32_t sub = (uint32_t)tid % kBacksubLanes;
+    double mcc = 0.0, st2 = 0.0, x2 = 0.0, gd = 0.0, gm = 0.0, rho = 0.0;
+    const bool live = p < n_pt;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    uint32_t q0 = 0, q1 = 0;
+    double x[3] = {0.0, 0.0, 0.0};
+    if (live) {
+        x[0] = pts[3 * (size_t)p]; x[1] = pts[3 * (size_t)p + 1]; x[2] = pts[3 * (size_t)p + 2];
+        q0 = pt_start[p]; q1 = pt_start[p + 1];
+#pragma unroll 2
+        for (uint32_t q = q0 + sub; q < q1; q += kBacksubLanes) {
+            const size_t k = pt_obs[q];
+            const size_t cam = q_cam[q];
+            const double2* row = reinterpret_cast<const double2*>(ar + kArG * k);
+            const double* pc = campre + kPoseStride * cam;
+            const double* d = s_w + 6 * cam;
+            double G[6], R[10];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { const double2 v2 = row[i]; G[2 * i] = v2.x; G[2 * i + 1] = v2.y; }
+#pragma unroll
+            for (int i = 0; i < 5; i++) { const double2 v2 = reinterpret_cast<const double2*>(pc)[i]; R[2 * i] = v2.x; R[2 * i + 1] = v2.y; }
+            const bool small = pc[21] != 0.0;
+            const double w0 = d[0], w1 = d[1], w2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
+            double v[3];
+            compact_v(R, small, x, v);
+            const double u0 = w1 * v[2] - w2 * v[1] + d3, u1 = w2 * v[0] - w0 * v[2] + d4, u2 = w0 * v[1] - w1 * v[0] + d5;
+            const double z0 = G[0] * u0 + G[1] * u1 + G[2] * u2;     // G u = A^T (A u)
+            const double z1 = G[1] * u0 + G[3] * u1 + G[4] * u2;
+            const double z2 = G[2] * u0 + G[4] * u1 + G[5] * u2;
+            t0 += R[0] * z0 + R[3] * z1 + R[6] * z2;
+            t1 += R[1] * z0 + R[4] * z1 + R[7] * z2;
+            t2 += R[2] * z0 + R[5] * z1 + R[8] * z2;
+        }
+    }
+    t0 = group_sum<kBacksubLanes>(t0); t1 = group_sum<kBacksubLanes>(t1); t2 = group_sum<kBacksubLanes>(t2);   // (in every lane of the group)
+    double xn[3] = {0.0, 0.0, 0.0};
+    if (live) {
+        const double g[3] = {gp[3 * (size_t)p], gp[3 * (size_t)p + 1], gp[3 * (size_t)p + 2]};
+        t0 += g[0]; t1 += g[1]; t2 += g[2];
+        const double* ci = Cinv + 6 * (size_t)p;
+        const double e[3] = {-(ci[0] * t0 + ci[1] * t1 + ci[2] * t2), -(ci[1] * t0 + ci[3] * t1 + ci[4] * t2),
+                             -(ci[2] * t0 + ci[4] * t1 + ci[5] * t2)};
+#pragma unroll
+        for (int a = 0; a < 3; a++) xn[a] = fmin(fmax(x[a] + e[a], bound_lo), bound_hi);
+        if (sub == 0) {
+            const double* Cp = C + 6 * (size_t)p;
+            const double cd[3] = {Cp[0], Cp[3], Cp[5]};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double st = xn[a] - x[a];
+                pts_out[3 * (size_t)p + a] = xn[a];
+                dp_out[3 * (size_t)p + a] = e[a];
+                mcc += 0.5 * (point_lambda(cd[a], sp[3 * (size_t)p + a], lm) * e[a] * e[a] - g[a] * e[a]);
+                st2 += st * st;
+                x2 += x[a] * x[a];
+                gd += g[a] * e[a];
+                gm = fmax(gm, fabs(g[a]));
+            }
+        }
+        // the candidate's residuals, the group's lanes sharing the observations again; pose table of the candidate cameras in LDS
+        for (uint32_t q = q0 + sub; q < q1; q += kBacksubLanes) {
+            PosePre pr;
+            pose_load(s_pre + kPoseStride * (size_t)q_cam[q], pr);
+            rho += residual_cost(pr, xn, uv[pt_obs[q]], P, delta);
+        }
+    }
+    mcc = wave_sum(mcc); st2 = wave_sum(st2); x2 = wave_sum(x2); gd = wave_sum(gd); gm = wave_max(gm); rho = wave_sum(rho);
+    if (tid % kWave == 0) {
+        double* o = red + (tid / kWave) * 6;
+        o[0] = mcc; o[1] = st2; o[2] = x2; o[3] = gd; o[4] = gm; o[5] = rho;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0, b = 0, c = 0, d = 0, e = 0, r = 0;
+        for (int w = 0; w < kPointBlock / kWave; w++) {
+            a += red[w * 6]; b += red[w * 6 + 1]; c += red[w * 6 + 2]; d += red[w * 6 + 3]; e = fmax(e, red[w * 6 + 4]); r += red[w * 6 + 5];
+        }
+        double* o = part + 5 * (size_t)blockIdx.x;
+        put(o, a); put(o + 1, b); put(o + 2, c); put(o + 3, d); put(o + 4, e);
+        put(cost_part + blockIdx.x, r);
+    }
+    if (!with_sums) return;
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int before = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = before == gridDim.x - 1 ? 1 : 0;
+        if (s_last) __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    step_sums_body<kPointBlock, true>(sums, red, fin);
+}
+
+bool apply_small_fits(uint32_t n_cam, uint32_t n_pt) { return n_cam >= 1 && n_cam <= (uint32_t)kApplySmallCams && n_pt >= 1; }
+
+void launch_apply_small(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams, const double* dc_free, const double* lc,
+                        const double* gc_red, const double* lin_resid, double* cams_out, double* dc_full, double* dcw, double* cam_part,
+                        double* campre_c, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam, const double* ar,
+                        const double* campre, const double* Cinv, const double* C, const double* gp, const double* sp, const double* pts, LmDiag lm,
+                        double bound_lo, double bound_hi, double* pts_out, double* dp, double* part, const float4* uv, const Proj& P, double delta,
+                        double* cost_part, unsigned int* arrivals, const StepSumsLaunch* sums)
+{
+    StepSumsArgs q{};
+    if (sums)
+        q = StepSumsArgs{part, backsub_blocks(n_pt), sums->out5, cam_part, 1u, sums->out_cam5, cost_part, backsub_blocks(n_pt), sums->out_cost,
+                         StepGate{sums->gate, sums->status, sums->x_cost, sums->min_relative_decrease, sums->gate_enabled, sums->armijo_in_gate},
+                         sums->stop_vote, Publish{sums->pub_src, sums->host_dst, sums->host_seq, sums->seq, sums->n_pub, sums->clear_first, sums->clear_n}};
+    hipLaunchKernelGGL(ba_apply_small_kernel, dim3(backsub_blocks(n_pt)), dim3(kPointBlock), 0, s, n_cam, cam_free, cams, dc_free, lc, gc_red,
+                       lin_resid, cams_out, dc_full, dcw, cam_part, campre_c, n_pt, pt_start, pt_obs, q_cam, ar, campre, Cinv, C, gp, sp, pts, lm,
+                       bound_lo, bound_hi, pts_out, dp, part, uv, P, delta, cost_part, arrivals, q, sums ? 1 : 0);
 }
 
 void launch_backsub(hipStream_t s, uint32_t n_pt, const uint32_t* pt_start, const uint32_t* pt_obs, const uint32_t* q_cam,

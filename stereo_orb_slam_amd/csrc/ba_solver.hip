@@ -153,6 +153,7 @@ struct soslam_ba {
     double* ps_host = nullptr;          // pinned: record (PSV_COUNT) + sequence word + iteration log of the resident structure-only solve
     int ps_host_entries = 0;
     DevBuf<double> ps_log;              // the same log on the device while the kernel runs
+    DevBuf<unsigned int> arrivals;      // ba_apply_small: arrival counter of its workgroups (zero between launches)
     DevBuf<double> ps_sync;             // its grid barrier: [2][kPointsOnlyMax / 64][16] partial-sum records, then the arrival counter
     unsigned long long ps_sync_base = 0;   // value of that counter between launches
 
@@ -909,7 +910,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(h->ar.alloc((size_t)n_obs * kArRow));
     SOSLAM_CHECK(h->dcw.alloc((size_t)n_cam * 6));
     SOSLAM_CHECK(h->tile_part.alloc((size_t)h->n_tiles * kTileVals));
-    SOSLAM_CHECK(h->cost_part.alloc(h->n_tiles));
+    SOSLAM_CHECK(h->cost_part.alloc(std::max<size_t>(h->n_tiles, backsub_blocks(n_pt))));   // (one entry per ba_cost tile, or per workgroup of ba_apply_small)
     SOSLAM_CHECK(h->C.alloc((size_t)n_pt * 6));
     SOSLAM_CHECK(h->gp.alloc((size_t)n_pt * 3));
     SOSLAM_CHECK(h->sp.alloc((size_t)n_pt * 3));
@@ -1198,7 +1199,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
         SOSLAM_HIP_CHECK(hipGetLastError());
         return wait_host_seq(h, h->host_seq, published);
     }
-    bool damp_fused = false;
+    bool damp_fused = false, apply_fused = false, sums_fused = false;
     {
         StageScope sc(h, SOSLAM_STAGE_SCHUR);
         run_schur(h, lm);
@@ -1355,19 +1356,43 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
                 resid = h->lin_resid.p;
             }
         }
+        // few cameras (the reference's windows), one rank: candidate cameras, back-substitution and candidate cost are ONE launch
+        static const bool no_fuse = std::getenv("SOSLAM_NO_APPLY_FUSE") != nullptr;   // development / tests
+        apply_fused = !no_fuse && !h->collective() && apply_small_fits(h->n_cam, h->n_pt);
+        if (apply_fused) {
+            // ... and the workgroup that finishes last sums the step scalars, tests acceptance and publishes (ba_step_sums' work)
+            static const bool no_sums = std::getenv("SOSLAM_NO_SUMS_FUSE") != nullptr;   // development / tests
+            sums_fused = !no_sums;
+            StepSumsLaunch sl{};
+            if (sums_fused) {
+                if (!h->arrivals.p) { SOSLAM_CHECK(h->arrivals.alloc(4)); SOSLAM_CHECK(h->arrivals.zero(s)); }
+                published = ++h->publish_seq;
+                const bool spec = speculate && h->x_cost_known;
+                sl = StepSumsLaunch{h->scalp() + SC_MCC_PTS, h->scalp() + SC_MCC_CAM, h->scalp() + SC_CAND_COST, h->scalp() + SC_GATE,
+                                    h->scalp() + SC_LIN_ITERS, h->x_cost, h->opt.min_relative_decrease, spec ? 1 : 0, stop_vote ? 1.0 : 0.0,
+                                    h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, h->host_raw, h->host_seq, published, is_constrained(h) ? 1 : 0};
+                speculated = spec;
+            }
+            launch_apply_small(s, h->n_cam, h->cam_free.p, h->cams[h->cur].p, h->dc_free.p, h->lc.p, h->gc_red(), resid, h->cams[h->cur ^ 1].p,
+                               h->dc_full.p, h->dcw.p, h->cam_part.p, h->campre_c.p, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p,
+                               h->campre.p, h->Cinv.p, h->C.p, h->gp.p, h->sp.p, h->pts[h->cur].p, lm, h->opt.lower_bound, h->opt.upper_bound,
+                               h->pts[h->cur ^ 1].p, h->dp.p, h->part.p, h->uv.p, h->proj, h->opt.huber_delta, h->cost_part.p, h->arrivals.p,
+                               sums_fused ? &sl : nullptr);
+        } else
         launch_cam_update(s, h->n_cam, h->cam_free.p, h->cams[h->cur].p, h->dc_free.p, h->lc.p, h->gc_red(), resid, h->campre.p,
                           h->cams[h->cur ^ 1].p, h->dc_full.p, h->dcw.p, h->cam_part.p, h->campre_c.p);
     }
-    {
+    if (!apply_fused) {
         StageScope sc(h, SOSLAM_STAGE_BACKSUB);
         launch_backsub(s, h->n_pt, h->pt_start.p, h->pt_obs.p, h->q_cam.p, h->ar.p, h->campre.p, h->dcw.p, h->Cinv.p, h->C.p,
                        h->gp.p, h->sp.p, h->pts[h->cur].p, lm, h->opt.lower_bound, h->opt.upper_bound, h->pts[h->cur ^ 1].p,
                        h->dp.p, h->part.p);
     }
-    {
+    if (!sums_fused) {
         StageScope sc(h, SOSLAM_STAGE_COST);
         // the candidate has its own pose table (written by ba_cam_update): campre stays at the linearisation point, the
         // compact rows need it; an accepted step swaps the two tables instead of preparing the same poses again
+        if (!apply_fused)
         launch_cost(s, h->n_tiles, h->tiles.p, h->uv.p, h->obs_pt.p, h->campre_c.p, h->pts[h->cur ^ 1].p, h->proj,
                     h->opt.huber_delta, h->cost_part.p);
         // one launch for the back-substitution's step scalars and the candidate cost; on a single rank nothing follows
@@ -1380,7 +1405,7 @@ int take_step(soslam_ba* h, double radius, bool speculate = false, bool stop_vot
         static_assert(SC_LIN_STATUS == SC_LIN_ITERS + 2 && SC_SCHUR_STATUS == SC_LIN_ITERS + 3, "status words as StepGate reads them");
         static_assert(SC_STOP == SC_MCC_PTS + 5 && SC_STOP == SC_GMAX_PTS + 1, "the stop vote follows the five step scalars");
         launch_step_sums(s, h->part.p, h->n_point_blocks, h->scalp() + SC_MCC_PTS, h->cam_part.p, cam_update_blocks(h->n_cam),
-                         h->scalp() + SC_MCC_CAM, h->cost_part.p, h->n_tiles, h->scalp() + SC_CAND_COST, h->scalp() + SC_GATE,
+                         h->scalp() + SC_MCC_CAM, h->cost_part.p, apply_fused ? h->n_point_blocks : h->n_tiles, h->scalp() + SC_CAND_COST, h->scalp() + SC_GATE,
                          h->scalp() + SC_LIN_ITERS, h->x_cost, h->opt.min_relative_decrease, (spec && !h->collective()) ? 1 : 0,
                          stop_vote ? 1.0 : 0.0, h->tail(), 4 + SC_COUNT, 4 + SC_LIN_ITERS, 4, published ? h->host_raw : nullptr, h->host_seq,
                          published, is_constrained(h) ? 1 : 0);
