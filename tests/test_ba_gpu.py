@@ -1044,6 +1044,37 @@ def test_two_block_dense_solve_matches_the_blocked_cholesky(gpu):
             np.testing.assert_allclose(new["pts"], old["pts"], rtol=1e-7, atol=1e-9)
 
 
+def test_fused_launches_of_small_problems_match_the_separate_ones(gpu):
+    """At most 32 cameras on one rank: candidate cameras, back-substitution, candidate cost and the step sums are one launch
+    (ba_apply_small; its last workgroup sums and publishes).  The separate launches it replaces (SOSLAM_NO_APPLY_FUSE) and the
+    separate sum kernel (SOSLAM_NO_SUMS_FUSE) must give the same trajectory - a 20-frame window with its line search, and the
+    ten-camera stand-in of configs[0] on the band solver."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for gen, solver in (("synth.generate_ba(None, n_cam=20, n_pt=3000, track_mode=1, track_len=6)", 0), ("synth.generate_ba(1)", 3)):
+        code = ("import json, sys; sys.path.insert(0, %r)\n"
+                "from stereo_orb_slam_amd import ba, synth\n"
+                "p = %s\n"
+                "with ba.BundleAdjustment(ba.default_options(max_iterations=10, check_termination=0, linear_solver=%d)) as h:\n"
+                "    h.load(p); s = h.solve(); log = h.iteration_log(); cams, pts = h.get_state()\n"
+                "print(json.dumps({'cost': [e.cost for e in log], 'acc': [e.accepted for e in log], 'ls': s.line_search_steps,\n"
+                "                  'radius': [e.radius for e in log], 'cams': cams.ravel().tolist(), 'pts': pts.ravel().tolist()[:90]}))\n") % (root, gen, solver)
+        outs = []
+        for env_extra in ({}, {"SOSLAM_NO_SUMS_FUSE": "1"}, {"SOSLAM_NO_APPLY_FUSE": "1"}):
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        old = outs[-1]
+        for new in outs[:-1]:
+            assert new["acc"] == old["acc"] and new["ls"] == old["ls"] and len(new["cost"]) >= 6
+            np.testing.assert_allclose(new["cost"], old["cost"], rtol=1e-10)
+            np.testing.assert_allclose(new["radius"], old["radius"], rtol=1e-8)
+            np.testing.assert_allclose(new["cams"], old["cams"], rtol=1e-7, atol=1e-9)
+            np.testing.assert_allclose(new["pts"], old["pts"], rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("tag", ["reject", "bounds"])
 @pytest.mark.parametrize("solver", [1, 2])
 def test_trust_region_trajectory_matches_the_independent_restatement(gpu, golden_dir, tag, solver):
