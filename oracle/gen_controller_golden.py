@@ -96,12 +96,13 @@ def armijo(evaluate, f0, g0, f1, dmax):
     return current["x"], it
 
 
-def ba_trajectory(problem, iters, lo, hi, radius0=1e4):
+def ba_trajectory(problem, iters, lo, hi, radius0=1e4, structure_only=False):
+    """structure_only: every camera constant (BundleAdjuster::Optimize(n-1, n), slam.cpp:123) - the unknowns are the points."""
     oc, op, uv, cams, pts = problem
     cams, pts = cams.copy(), np.clip(pts, lo, hi)
     n_cam, n_pt = len(cams), len(pts)
-    nc6 = 6 * n_cam - 6
-    free = np.arange(6, 6 * n_cam + 3 * n_pt)
+    nc6 = 0 if structure_only else 6 * n_cam - 6
+    free = np.arange(6 * n_cam if structure_only else 6, 6 * n_cam + 3 * n_pt)
     radius, dec = radius0, 2.0
     r, J, cost = G.robust_blocks(oc, op, uv, cams, pts)
     Jf = J[:, free]
@@ -120,7 +121,9 @@ def ba_trajectory(problem, iters, lo, hi, radius0=1e4):
             radius *= 0.5
             rec.append(e)
             continue
-        dc = np.zeros((n_cam, 6)); dc.reshape(-1)[6:] = delta[:nc6]
+        dc = np.zeros((n_cam, 6))
+        if not structure_only:
+            dc.reshape(-1)[6:] = delta[:nc6]
         dp = delta[nc6:].reshape(n_pt, 3)
         g = Jf.T @ r
         gdot = float(g @ delta)
@@ -179,6 +182,16 @@ def gen_ba(rng):
           "final cost", cost)
     out.update({"bounds_" + k: v for k, v in traj.items()})
     out.update(bounds_cams0=cams0, bounds_pts0=np.clip(pts0 * 1.04, -B, B), bounds_cams=cams, bounds_pts=pts, bounds_final_cost=cost, bounds_lo=-B, bounds_hi=B)
+    # (3) structure only (every camera constant: the per-frame call), bounds active: the device runs this one resident - controller
+    # and line search in the kernel.  The draw has both outcomes of the search: two iterations whose search gives up after 14
+    # contractions (the step stays, is judged and rejected) and two whose search succeeds at once (step size 0.2)
+    # (a generator of its own: the pose-graph fixture below keeps the stream it was made with)
+    pts_far = pts0 * (1 + np.random.default_rng(20241008).normal(0, 0.25, (len(pts0), 1)))
+    traj, cams, pts, cost = ba_trajectory((oc, op, uv, cams0, pts_far), 12, -B, B, structure_only=True)
+    print("points run: accepted", traj["accepted"].tolist(), "alpha", np.array2string(traj["alpha"], precision=4), "ls iters", traj["ls_iters"].tolist(),
+          "final cost", cost)
+    out.update({"points_" + k: v for k, v in traj.items()})
+    out.update(points_cams0=cams0, points_pts0=np.clip(pts_far, -B, B), points_cams=cams, points_pts=pts, points_final_cost=cost, points_lo=-B, points_hi=B)
     np.savez(os.path.join(OUT, "ba_lm_trajectory.npz"), **out)
 
 

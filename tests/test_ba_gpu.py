@@ -1075,7 +1075,7 @@ def test_fused_launches_of_small_problems_match_the_separate_ones(gpu):
             np.testing.assert_allclose(new["pts"], old["pts"], rtol=1e-7, atol=1e-9)
 
 
-@pytest.mark.parametrize("tag", ["reject", "bounds"])
+@pytest.mark.parametrize("tag", ["reject", "bounds", "points"])
 @pytest.mark.parametrize("solver", [1, 2])
 def test_trust_region_trajectory_matches_the_independent_restatement(gpu, golden_dir, tag, solver):
     """The device path's controller against the numpy / autograd restatement of the whole loop (oracle/gen_controller_golden.py;
@@ -1087,6 +1087,8 @@ def test_trust_region_trajectory_matches_the_independent_restatement(gpu, golden
     n = len(g[tag + "_radius"])
     fixed = np.zeros(len(g[tag + "_cams0"]), np.uint8)
     fixed[0] = 1
+    if tag == "points":
+        fixed[:] = 1   # structure only: the whole loop runs in the resident kernel (ba_points_solve), its controller and line search included
     kw = dict(linear_solver=solver, max_iterations=n, check_termination=0, lower_bound=float(g[tag + "_lo"]), upper_bound=float(g[tag + "_hi"]),
               pcg_tolerance=1e-13)
     if tag + "_radius0" in g.files:

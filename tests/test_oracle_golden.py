@@ -151,23 +151,30 @@ def _ba_options(oracle_lib, g, tag):
     return kw
 
 
-@pytest.mark.parametrize("tag", ["reject", "bounds"])
+@pytest.mark.parametrize("tag", ["reject", "bounds", "points"])
 def test_trust_region_trajectory_matches_the_independent_restatement(oracle_lib, golden_dir, tag):
     """Radius sequence through accepted and rejected steps ("reject": 14 iterations, five rejections, factors 2, 4, growth through
     1 / max(1/3, 1 - (2 rho - 1)^3)) and the bounded problem's Armijo search with cubic interpolation ("bounds": three
-    iterations whose full projected step fails the sufficient-decrease test and is contracted to 0.21..) - every iteration's
-    radius, model cost change, candidate cost, step quality and step norm against the numpy / autograd restatement."""
+    iterations whose full projected step fails the sufficient-decrease test and is contracted to 0.21..; "points": the same with
+    every camera constant - the per-frame call, slam.cpp:123 -, two searches that succeed and two that give up after 14 contractions) - every iteration's radius, model
+    cost change, candidate cost, step quality and step norm against the numpy / autograd restatement."""
     g = _load(golden_dir, "ba_lm_trajectory.npz")
     fixed = np.zeros(len(g[tag + "_cams0"]), np.uint8)
     fixed[0] = 1
+    if tag == "points":
+        fixed[:] = 1
     o = oracle_lib.default_options(**_ba_options(oracle_lib, g, tag))
     cams, pts, summ, log = oracle_lib.solve(g["obs_cam"], g["obs_pt"], g["obs_uv"], g[tag + "_cams0"], g[tag + "_pts0"], g["proj_l"],
                                             g["proj_r"], fixed, o)
     _check_ba_trajectory(g, tag, log, summ.line_search_steps, summ.final_cost, cams)
     if tag == "reject":
         assert (g["reject_accepted"] == 0).sum() >= 4
-    else:
-        assert (g["bounds_alpha"] < 1.0).sum() >= 3 and g["bounds_ls_iters"].sum() >= 3
+    elif tag == "bounds":
+        assert (g[tag + "_alpha"] < 1.0).sum() >= 3 and g[tag + "_ls_iters"].sum() >= 3
+    if tag == "points":
+        # both outcomes of the search: contractions that succeed, and searches that give up after 14 (the step is then rejected)
+        assert (g["points_alpha"] < 1.0).sum() >= 2 and (g["points_ls_iters"] >= 13).sum() >= 2 and (g["points_accepted"] == 0).sum() >= 2
+        np.testing.assert_allclose(pts, g["points_pts"], atol=1e-7)
 
 
 def test_levenberg_schedule_matches_the_independent_restatement(oracle_lib, golden_dir):
