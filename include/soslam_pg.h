@@ -28,9 +28,13 @@ extern "C" {
 
 enum { SOSLAM_PG_TERM_ITERATIONS = 0, SOSLAM_PG_TERM_TRIALS = 1, SOSLAM_PG_TERM_FAILURE = 2 };
 /* preconditioner of the PCG that stands in for g2o's LinearSolverEigen (a direct sparse Cholesky,
- * /root/reference/src/pose_graph_optimizer.cpp:14-18): block-Jacobi, or block-Jacobi plus a coarse space of six rigid-body modes
- * per aggregate of neighbouring vertices (two-level; AUTO takes it from 256 free vertices on) */
-enum { SOSLAM_PG_PRECOND_AUTO = 0, SOSLAM_PG_PRECOND_BLOCK_JACOBI = 1, SOSLAM_PG_PRECOND_TWO_LEVEL = 2 };
+ * /root/reference/src/pose_graph_optimizer.cpp:14-18): block-Jacobi; block-Jacobi plus a coarse space of six rigid-body modes
+ * per aggregate of neighbouring vertices (two-level); or - a chain of keyframes with a few loop closures, the reference's own
+ * graphs - the exact factor of the band that holds the odometry chain (block cyclic reduction), the closure blocks staying in
+ * the matrix-vector product only.  AUTO: the band factor when at least 99 % of the edges join vertices at most ten apart in the
+ * order given and at most four do not (every closure costs that PCG about a dozen rounds), else two-level from 64 free vertices
+ * on, else block-Jacobi */
+enum { SOSLAM_PG_PRECOND_AUTO = 0, SOSLAM_PG_PRECOND_BLOCK_JACOBI = 1, SOSLAM_PG_PRECOND_TWO_LEVEL = 2, SOSLAM_PG_PRECOND_BAND_FACTOR = 3 };
 
 typedef struct soslam_pg_options {
     int32_t max_iterations;      /* 10: optimize(10), /root/reference/src/pose_graph_optimizer.cpp:69 */

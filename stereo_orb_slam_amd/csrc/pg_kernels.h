@@ -27,6 +27,9 @@ void launch_pg_gather(hipStream_t s, uint32_t n_blocks, const uint32_t* ptr, con
 void launch_pg_chi2(hipStream_t s, uint32_t n_edge, const double* est, const uint32_t* ef, const uint32_t* et,
                     const double* meas, const PgInfo& info, double delta, double* chi_part);
 // out[0] = sum(part[0..n)); if diag_block: out[1] = max |diag(H)|
+// H += delta I on the free vertices' diagonal blocks (the band-factor path keeps the Levenberg shift inside H: the factorisation
+// and the PCG's matrix-vector product both read the shifted matrix)
+void launch_pg_shift_diag(hipStream_t s, double* H, const int32_t* diag_block, uint32_t n_free, double delta);
 void launch_pg_reduce(hipStream_t s, const double* part, uint32_t n, const double* H, const int32_t* diag_block, uint32_t n_free,
                       double* out);
 void launch_pg_update(hipStream_t s, uint32_t n_vertex, const double* est, const int32_t* free_idx, const double* x,

@@ -404,4 +404,16 @@ void launch_pg_coarse_basis(hipStream_t s, uint32_t n_free, const uint32_t* free
     hipLaunchKernelGGL(pg_coarse_basis_kernel, dim3((n_free + 255) / 256), dim3(256), 0, s, n_free, free_vertex, row_agg, agg_ref, est, P);
 }
 
+__global__ __launch_bounds__(256) void pg_shift_diag_kernel(double* __restrict__ H, const int32_t* __restrict__ diag_block, uint32_t n_free,
+                                                            const double delta)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_free * 6) H[36 * (size_t)diag_block[i / 6] + 7 * (i % 6)] += delta;
+}
+
+void launch_pg_shift_diag(hipStream_t s, double* H, const int32_t* diag_block, uint32_t n_free, double delta)
+{
+    if (n_free) hipLaunchKernelGGL(pg_shift_diag_kernel, dim3((n_free * 6 + 255) / 256), dim3(256), 0, s, H, diag_block, n_free, delta);
+}
+
 }  // namespace soslam

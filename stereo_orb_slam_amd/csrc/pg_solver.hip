@@ -8,6 +8,7 @@
 #include <memory>
 
 #include "common.h"
+#include "ba_kernels.h"   // the SC_* slots the band solver reports through
 #include "linsolve.h"
 #include "pg_kernels.h"
 #include "soslam_pg.h"
@@ -46,6 +47,15 @@ struct soslam_pg {
     hipEvent_t ev_coarse_in = nullptr, ev_coarse_done = nullptr;
     int cinv_cur = 0;
     bool cinv_valid = false, cinv_pending = false;
+    // chain-shaped graphs (the reference's: keyframes in order, a few loop closures): the band of the odometry chain factored
+    // exactly by block cyclic reduction, the closure blocks left to the PCG's matrix-vector product (the BA path's treatment of
+    // loop closures).  The band part of H is positive definite by itself: dropping a closure edge's OFF-diagonal
+    // block leaves its two diagonal contributions, which are positive semidefinite
+    bool band_mode = false, band_off = false;
+    int band_bw = 0, band_rounds = 2;
+    double applied_shift = 0.0;         // the Levenberg shift currently inside H's diagonal (band mode)
+    DevBuf<int32_t> cr_map;
+    DevBuf<double> cr_ws, lin_scal;
     int cur = 0;
     double setup_seconds = 0.0;
     std::vector<soslam_pg_iteration> log;
@@ -96,7 +106,42 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     // an aggregate is a contiguous range of block rows of H.
     constexpr uint32_t kAggMax = 42;   // block rows of one pcg2 workgroup
     const int pre = h->opt.preconditioner;
-    h->two_level = nf > 0 && (pre == SOSLAM_PG_PRECOND_TWO_LEVEL || (pre == SOSLAM_PG_PRECOND_AUTO && nf >= 64)) && (nf + kAggMax - 1) / kAggMax * 6 <= 1200;
+    // a chain?  offsets of the edges' vertices in the order given (the reference numbers keyframes as they arrive)
+    h->band_mode = false; h->band_off = false; h->band_bw = 0;
+    if (nf >= 32 && (pre == SOSLAM_PG_PRECOND_AUTO || pre == SOSLAM_PG_PRECOND_BAND_FACTOR) && std::getenv("SOSLAM_PG_NO_BAND") == nullptr) {
+        uint64_t within[kCrBandMax + 1] = {0}, pairs = 0;
+        for (uint32_t k = 0; k < n_edge; k++) {
+            const int32_t a = h->h_free[ef[k]], b = h->h_free[et[k]];
+            if (a < 0 || b < 0) continue;
+            pairs++;
+            const uint32_t d = (uint32_t)std::abs(a - b);
+            if (d <= (uint32_t)kCrBandMax) within[d]++;
+        }
+        uint64_t acc = 0;
+        int w = 0;
+        for (w = 1; w <= kCrBandMax; w++) {
+            acc += within[w];
+            if (acc * 100 >= pairs * 99) break;
+        }
+        if (pre == SOSLAM_PG_PRECOND_BAND_FACTOR && w > kCrBandMax) w = kCrBandMax;   // asked for: whatever lies outside stays in the matvec
+        if (pairs > 0 && w <= kCrBandMax) {
+            h->band_mode = true;
+            // super-blocks of nine vertices whatever the chain's own width (a tridiagonal chain factored in 6 x 6 nodes would be a
+            // tree of log2(n) levels of tiny inverses): ten only when the band needs it
+            h->band_bw = w <= 9 ? 9 : kCrBandMax;
+            uint64_t inside = 0;
+            for (int d = 1; d <= h->band_bw; d++) inside += within[d];
+            h->band_off = inside < pairs;
+            h->band_rounds = 2;
+            // Every closure left to the matrix-vector product costs the PCG about a dozen rounds (it perturbs the preconditioned
+            // matrix by rank 12, and not by little), a round 95 us at 2 000 vertices against 18 us for an iteration of the two-level
+            // PCG, which needs ~270 of them on such a chain whatever the closures: measured (scripts/pg_chain_probe.py, ten
+            // iterations) 14 / 23 / 31 / 35 / 48 / 68 ms at 1 / 2 / 3 / 4 / 6 / 12 closures against 44-49 ms.  AUTO takes the band up to
+            // four closures - the first loops of a run, which is when the reference calls this
+            if (pre == SOSLAM_PG_PRECOND_AUTO && pairs - inside > 4) h->band_mode = false;
+        }
+    }
+    h->two_level = !h->band_mode && nf > 0 && (pre == SOSLAM_PG_PRECOND_TWO_LEVEL || (pre == SOSLAM_PG_PRECOND_AUTO && nf >= 64)) && (nf + kAggMax - 1) / kAggMax * 6 <= 1200;
     std::vector<uint32_t> agg_ptr, row_agg, agg_ref, free_vertex(nf);
     if (h->two_level) {
         std::vector<std::vector<uint32_t>> adj(n_vertex);
@@ -275,7 +320,15 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     SOSLAM_CHECK(h->x.alloc((size_t)nf * 6));
     SOSLAM_CHECK(h->x.zero(s));
     SOSLAM_CHECK(h->resid.alloc((size_t)nf * 6));
-    SOSLAM_CHECK(h->work.alloc(std::max(pcg_multi_work_count(nf), pcg2_work_count(nf, h->n_agg))));
+    SOSLAM_CHECK(h->work.alloc(std::max({pcg_multi_work_count(nf), pcg2_work_count(nf, h->n_agg), h->band_mode ? pcg_band_work_count(nf) : (size_t)0})));
+    if (h->band_mode) {
+        std::vector<int32_t> map(cr_map_count(nf, h->band_bw));
+        cr_build_map(nf, h->band_bw, h->n_blocks, h->h_blk_row.data(), h->h_blk_col.data(), map.data());
+        SOSLAM_CHECK(h->cr_map.upload(map, s));
+        SOSLAM_CHECK(h->cr_ws.alloc(cr_count(nf, h->band_bw)));
+        SOSLAM_CHECK(h->lin_scal.alloc(SC_COUNT + 8));
+        SOSLAM_CHECK(h->lin_scal.zero(s));
+    }
     if (h->two_level) {
         SOSLAM_CHECK(h->agg_ptr.upload(agg_ptr, s));
         SOSLAM_CHECK(h->row_agg.upload(row_agg, s));
@@ -330,6 +383,7 @@ int linearize(soslam_pg* h, double* dbg_e, double* dbg_ji, double* dbg_jj)
                         h->chi_part_lin.p, dbg_e, dbg_ji, dbg_jj);
     launch_pg_gather(s, h->n_blocks, h->g_ptr.p, h->g_ent.p, h->blk_row.p, h->blk_col.p, h->econ.p, h->H.p, h->b.p);
     launch_pg_reduce(s, h->chi_part_lin.p, h->n_chi_part, h->H.p, h->diag_block.p, h->n_free, h->scal.p);
+    h->applied_shift = 0.0;   // H is rebuilt
     if (h->two_level && h->cinv_pending) {
         // the coarse inverse under way on the second stream read Ac0 and G: they are rewritten below
         SOSLAM_HIP_CHECK(hipStreamWaitEvent(s, h->ev_coarse_done, 0));
@@ -392,7 +446,29 @@ int run(soslam_pg* h, soslam_pg_summary* out)
             double rel = 0.0;
             int lin_it = 0;
             SOSLAM_HIP_CHECK(hipEventRecord(h->ev[0], s));
-            if (h->n_free && h->two_level) {
+            if (h->n_free && h->band_mode) {
+                // the shift into H (the difference to what a previous trial of this iteration left there), the band's factor - which
+                // carries b down its tree -, PCG rounds until the tolerance: one round when every block lies inside the band
+                if (lambda != h->applied_shift) launch_pg_shift_diag(s, h->H.p, h->diag_block.p, h->n_free, lambda - h->applied_shift);
+                h->applied_shift = lambda;
+                SOSLAM_HIP_CHECK(hipMemsetAsync(h->lin_scal.p + SC_LIN_ITERS, 0, 3 * sizeof(double), s));
+                launch_cr_factor(s, bsr_view(h), h->cr_map.p, h->band_bw, h->cr_ws.p, h->lin_scal.p, nullptr, h->b.p);
+                int enq = std::min(o.pcg_max_iterations, h->band_off ? h->band_rounds : 2);
+                launch_pcg_cr(s, bsr_view(h), h->band_bw, h->cr_ws.p, h->b.p, h->x.p, h->resid.p, h->work.p, o.pcg_tolerance, enq, h->lin_scal.p, true);
+                double lin[3] = {0.0, 0.0, 0.0};
+                while (true) {
+                    SOSLAM_HIP_CHECK(hipMemcpyAsync(lin, h->lin_scal.p + SC_LIN_ITERS, sizeof lin, hipMemcpyDeviceToHost, s));
+                    SOSLAM_HIP_CHECK(hipStreamSynchronize(s));
+                    if (lin[1] <= o.pcg_tolerance || lin[2] != 0.0 || enq >= o.pcg_max_iterations) break;
+                    const int more = std::min(o.pcg_max_iterations - enq, std::max(4, enq / 2));
+                    launch_pcg_cr_more(s, bsr_view(h), h->band_bw, h->cr_ws.p, h->x.p, h->resid.p, h->work.p, o.pcg_tolerance, more, h->lin_scal.p);
+                    enq += more;
+                }
+                static_assert(SC_LIN_RESID == SC_LIN_ITERS + 1 && SC_LIN_STATUS == SC_LIN_ITERS + 2, "the three slots read above");
+                lin_it = (lin[2] != 0.0 || !(lin[1] <= o.pcg_tolerance)) ? -1 : (int)lin[0];
+                rel = lin[1];
+                if (lin_it > 0) h->band_rounds = std::max(2, lin_it + 1);
+            } else if (h->n_free && h->two_level) {
                 if (h->cinv_pending) {   // a second trial of the same iteration: the inverse the first one started
                     SOSLAM_HIP_CHECK(hipStreamWaitEvent(s, h->ev_coarse_done, 0));
                     h->cinv_pending = false;
