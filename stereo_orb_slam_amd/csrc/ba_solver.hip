@@ -1786,7 +1786,13 @@ int run_points_resident(soslam_ba* h, int max_it, bool check, soslam_ba_summary*
     c.seq = ++h->publish_seq;
     h->scale_init = true;
     launch_points_solve(s, a, h->proj, c);
-    SOSLAM_CHECK(wait_host_seq(h, c.host_seq, c.seq));
+    if (const int rc = wait_host_seq(h, c.host_seq, c.seq)) {
+        // the record never came (a failed launch, a workgroup that never ran): the barrier's counter is unknown from here on
+        (void)hipStreamSynchronize(s);
+        (void)h->ps_sync.zero(s);
+        h->ps_sync_base = 0;
+        return rc;
+    }
     const double* r = h->ps_host;
     h->ps_sync_base += (unsigned long long)r[PSV_PASSES] * (unsigned long long)c.n_wg;
     if (r[PSV_ERROR] == 2.0) {
