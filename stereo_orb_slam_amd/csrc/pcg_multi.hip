@@ -282,11 +282,14 @@ __global__ __launch_bounds__(kThreads) void pcgm_update_kernel(const uint32_t n,
 // of at most 42 neighbouring vertices (P_i = the vertex's local increment under a rigid motion of its aggregate; the
 // coarse matrix is inverted explicitly by launch_dense_spd_inverse60, so applying it is one small dense product).  A CPU
 // prototype on configs[4] gave 368 iterations for block-Jacobi, 46 - 75 for this (aggregates of 25 - 100 vertices).
-// One workgroup per aggregate (the block rows of an aggregate are contiguous): three kernels per iteration -
-//   matvec   as pcgm_matvec;   update   alpha, x, r, the fine part D^-1 r and this aggregate's P^T r;
-//   coarse   y = (row block of the coarse inverse) . (P^T r of all aggregates), z = D^-1 r + P y, partial r.z.
+// One workgroup per aggregate (the block rows of an aggregate are contiguous): TWO kernels per iteration -
+//   matvec   as pcgm_matvec, plus this aggregate's P^T q;
+//   update   alpha, x, r, the fine part D^-1 r; P^T r of ALL aggregates by its recurrence P^T r - alpha P^T q (every workgroup
+//            for itself - what made the coarse part a third kernel was waiting for the other aggregates' P^T r);
+//            y = (row block of the coarse inverse) . (P^T r), z = D^-1 r + P y, partial r.r and r.z.
 struct Pcg2Bufs {
     double *p[2], *z, *q, *minv, *part_pq, *part_rz, *part_rr, *state;
+    double *rc[2], *qc;   // P^T r of every aggregate by iteration parity, P^T q of the current iteration (ncp entries each)
     uint32_t n_wg;
 };
 
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void pcg2_init_kernel(const BsrView A, co
     if (t < 6) {
         double s = 0.0;
         for (uint32_t v = 0; v < nr; v++) s += yl[v * 6 + t];
-        tl.rc[blockIdx.x * 6 + t] = s;
+        w.rc[0][blockIdx.x * 6 + t] = s;
     }
     const double bb = block_sum256(bi * bi, red);
     if (t == 0) {
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(kThreads) void pcg2_coarse_kernel(const double* __r
     }
     const int t = threadIdx.x;
     const uint32_t r0 = tl.agg_ptr[blockIdx.x], nr = tl.agg_ptr[blockIdx.x + 1] - r0;
-    for (uint32_t j = t; j < tl.ncp; j += kThreads) rcl[j] = tl.rc[j];
+    for (uint32_t j = t; j < tl.ncp; j += kThreads) rcl[j] = w.rc[0][j];
     __syncthreads();
     if (t < 240) {
         const int a = t / 40, s = t % 40;
@@ -394,16 +397,32 @@ __global__ __launch_bounds__(kThreads) void pcg2_matvec_kernel(const BsrView A, 
     const uint32_t r0 = tl.agg_ptr[blockIdx.x], nr = tl.agg_ptr[blockIdx.x + 1] - r0;
     const int t = threadIdx.x;
     const uint32_t i = r0 * 6 + t;
+    __shared__ double qloc[kRowsPerWg * 6], yl[kRowsPerWg * 6];
     double pq = 0.0;
-    if (t < (int)(nr * 6)) {
+    const bool act = t < (int)(nr * 6);
+    if (act) {
         const double pi = FIRST ? p_old[i] : w.z[i] + beta * p_old[i];
         if (!FIRST) w.p[parity][i] = pi;
         const double qi = bsr_row_dot_dir<FIRST>(A, i, w.z, p_old, beta) + shift * pi;
         w.q[i] = qi;
+        qloc[t] = qi;
         pq = pi * qi;
     }
-    pq = block_sum256(pq, red);
+    pq = block_sum256(pq, red);   // (its barriers: qloc is complete behind it)
     if (t == 0) w.part_pq[blockIdx.x] = pq;
+    // P^T q of this aggregate: the update kernels of ALL aggregates advance P^T r with it
+    if (act) {
+        const double* Pv = tl.P + 36 * (size_t)(i / 6);
+        const double* qv = qloc + (t / 6) * 6;
+        const int a = t % 6;
+        yl[t] = Pv[a] * qv[0] + Pv[6 + a] * qv[1] + Pv[12 + a] * qv[2] + Pv[18 + a] * qv[3] + Pv[24 + a] * qv[4] + Pv[30 + a] * qv[5];
+    }
+    __syncthreads();
+    if (t < 6) {
+        double sq = 0.0;
+        for (uint32_t v = 0; v < nr; v++) sq += yl[v * 6 + t];
+        w.qc[blockIdx.x * 6 + t] = sq;
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void pcg2_update_kernel(double* __restrict__ x, double* __restrict__ r, const Pcg2Bufs w,
@@ -411,7 +430,10 @@ __global__ __launch_bounds__(kThreads) void pcg2_update_kernel(double* __restric
 {
     __shared__ double red[4];
     __shared__ double red3[3][4];
-    __shared__ double rloc[kRowsPerWg * 6], yl[kRowsPerWg * 6];
+    __shared__ double rloc[kRowsPerWg * 6];
+    __shared__ double rcl[1280];          // P^T r of every aggregate (ncp <= 1260)
+    __shared__ double part[6][40];
+    __shared__ double y[6];
     if (w.state[ST_DONE] != 0.0) return;
     double rr_old, pq, rz;
     coop_sum3(w.part_rr + parity * w.n_wg, w.part_pq, w.part_rz + parity * w.n_wg, w.n_wg, red3, rr_old, pq, rz);
@@ -432,24 +454,46 @@ __global__ __launch_bounds__(kThreads) void pcg2_update_kernel(double* __restric
         r[i] = ri;
         rloc[t] = ri;
     }
+    // P^T r of every aggregate: the recurrence (P^T is linear in r), this workgroup's own six entries handed on
+    for (uint32_t j = t; j < tl.ncp; j += kThreads) {
+        const double v = w.rc[parity][j] - alpha * w.qc[j];
+        rcl[j] = v;
+        if (j / 6 == blockIdx.x) w.rc[parity ^ 1][j] = v;
+    }
     __syncthreads();
+    double zf = 0.0;
     if (act) {
         const double* M = w.minv + 36 * (size_t)(i / 6) + 6 * (i % 6);
         const double* rv = rloc + (t / 6) * 6;
-        w.z[i] = M[0] * rv[0] + M[1] * rv[1] + M[2] * rv[2] + M[3] * rv[3] + M[4] * rv[4] + M[5] * rv[5];   // the fine part; pcg2_coarse adds P y
-        const double* Pv = tl.P + 36 * (size_t)(i / 6);
-        const int a = t % 6;
-        yl[t] = Pv[a] * rv[0] + Pv[6 + a] * rv[1] + Pv[12 + a] * rv[2] + Pv[18 + a] * rv[3] + Pv[24 + a] * rv[4] + Pv[30 + a] * rv[5];
+        zf = M[0] * rv[0] + M[1] * rv[1] + M[2] * rv[2] + M[3] * rv[3] + M[4] * rv[4] + M[5] * rv[5];   // the fine part D^-1 r
+    }
+    if (t < 240) {
+        const int a = t / 40, sgrp = t % 40;
+        const double* row = tl.Ainv + (size_t)(blockIdx.x * 6 + a) * tl.ncp;
+        double sum = 0.0;
+        for (uint32_t j = sgrp; j < tl.ncp; j += 40) sum += row[j] * rcl[j];
+        part[a][sgrp] = sum;
     }
     __syncthreads();
     if (t < 6) {
-        double s = 0.0;
-        for (uint32_t v = 0; v < nr; v++) s += yl[v * 6 + t];
-        tl.rc[blockIdx.x * 6 + t] = s;
+        double sum = 0.0;
+#pragma unroll
+        for (int sgrp = 0; sgrp < 40; sgrp++) sum += part[t][sgrp];
+        y[t] = sum;
+    }
+    __syncthreads();
+    double rzn = 0.0;
+    if (act) {
+        const double* Pv = tl.P + 36 * (size_t)(i / 6) + 6 * (i % 6);
+        const double zi = zf + (Pv[0] * y[0] + Pv[1] * y[1] + Pv[2] * y[2] + Pv[3] * y[3] + Pv[4] * y[4] + Pv[5] * y[5]);
+        w.z[i] = zi;
+        rzn = ri * zi;
     }
     const double rr = block_sum256(ri * ri, red);
+    rzn = block_sum256(rzn, red);
     if (t == 0) {
         w.part_rr[(parity ^ 1) * w.n_wg + blockIdx.x] = rr;
+        w.part_rz[(parity ^ 1) * w.n_wg + blockIdx.x] = rzn;
         if (blockIdx.x == 0) w.state[ST_ITERS] += 1.0;
     }
 }
@@ -601,7 +645,7 @@ namespace soslam {
 size_t pcg2_work_count(uint32_t n_rows, uint32_t n_agg)
 {
     const size_t n = (size_t)n_rows * 6;
-    return 4 * n + 36 * (size_t)n_rows + 5 * (size_t)n_agg + ST_COUNT + 16;
+    return 4 * n + 36 * (size_t)n_rows + 5 * (size_t)n_agg + ST_COUNT + 16 + 3 * 1280;
 }
 
 // the coarse operator for a shift: (P^T A P + shift P^T P)^-1, explicit, into ainv_out ([ncp * ncp]); status[0] = 1 on a
@@ -628,8 +672,9 @@ int pcg2_solve(hipStream_t s, const BsrView& A, double shift, const double* b, d
     w.part_rz = w.part_pq + n_wg;
     w.part_rr = w.part_rz + 2 * (size_t)n_wg;
     w.state = w.part_rr + 2 * (size_t)n_wg;
+    w.rc[0] = w.state + ST_COUNT; w.rc[1] = w.rc[0] + 1280; w.qc = w.rc[1] + 1280;
     double* r = resid;
-    (void)hipMemsetAsync(w.state, 0, sizeof(double) * ST_COUNT, s);
+    (void)hipMemsetAsync(w.state, 0, sizeof(double) * (ST_COUNT + 3 * 1280), s);   // (the padding entries of P^T r and P^T q stay zero)
     hipLaunchKernelGGL(pcg2_init_kernel, dim3(n_wg), dim3(kThreads), 0, s, A, shift, b, x, r, w, tl);
     hipLaunchKernelGGL(pcgm_bb_kernel, dim3(1), dim3(64), 0, s, PcgBufs{{w.p[0], w.p[1]}, w.z, w.q, w.minv, w.part_pq, w.part_rz, w.part_rr, w.state, w.n_wg});
     hipLaunchKernelGGL(pcg2_coarse_kernel<true>, dim3(n_wg), dim3(kThreads), 0, s, r, w, tl, 0, tol);
@@ -638,13 +683,12 @@ int pcg2_solve(hipStream_t s, const BsrView& A, double shift, const double* b, d
     double rr = 0.0;
     while (launched < max_iter) {
         // the first chunk is the caller's estimate of the whole solve (the iterations its last solve took); what is left
-        // after it goes in short chunks: an unneeded launch costs 2 - 3 us, three per iteration
+        // after it goes in short chunks: an unneeded launch costs 2 - 3 us, two per iteration
         const int todo = std::min(launched == 0 ? std::max(chunk, 1) : 8, max_iter - launched);
         for (int k = 0; k < todo; k++) {
             if (launched + k == 0) hipLaunchKernelGGL(pcg2_matvec_kernel<true>, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, tl, parity, tol);
             else hipLaunchKernelGGL(pcg2_matvec_kernel<false>, dim3(n_wg), dim3(kThreads), 0, s, A, shift, w, tl, parity, tol);
             hipLaunchKernelGGL(pcg2_update_kernel, dim3(n_wg), dim3(kThreads), 0, s, x, r, w, tl, parity, tol);
-            hipLaunchKernelGGL(pcg2_coarse_kernel<false>, dim3(n_wg), dim3(kThreads), 0, s, r, w, tl, parity, tol);
             parity ^= 1;
         }
         launched += todo;
