@@ -150,6 +150,33 @@ struct soslam_ba {
     unsigned char* up_host[3] = {nullptr, nullptr, nullptr};   // pinned staging of the packed transfers (PackedSeg table, then payloads):
     size_t up_host_bytes[3] = {0, 0, 0};                       // the index arrays; the table of the fills (the first kernel may still be
                                                                // reading); the state, in and out (set_state / get_state)
+    // One pinned allocation serves the small buffers above and below (hipHostMalloc costs 0.15 - 0.25 ms a call: five of them were
+    // most of a one-shot per-frame call); what outgrows it gets an allocation of its own
+    unsigned char* pin_pool = nullptr;
+    size_t pin_pool_bytes = 0, pin_pool_used = 0;
+    int pinned_alloc(void** out, size_t bytes)
+    {
+        constexpr size_t kPool = 512u << 10;
+        if (!pin_pool) {
+            if (hipHostMalloc(reinterpret_cast<void**>(&pin_pool), kPool, hipHostMallocDefault) != hipSuccess) { pin_pool = nullptr; }
+            else { pin_pool_bytes = kPool; pin_pool_used = 0; }
+        }
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (pin_pool && pin_pool_used + need <= pin_pool_bytes) {
+            *out = pin_pool + pin_pool_used;
+            pin_pool_used += need;
+            return SOSLAM_OK;
+        }
+        SOSLAM_HIP_CHECK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+        return SOSLAM_OK;
+    }
+    void pinned_free(void* q)   // (a piece of the pool stays with the pool)
+    {
+        if (!q) return;
+        const unsigned char* u = static_cast<const unsigned char*>(q);
+        if (pin_pool && u >= pin_pool && u < pin_pool + pin_pool_bytes) return;
+        (void)hipHostFree(q);
+    }
     double* ps_host = nullptr;          // pinned: record (PSV_COUNT) + sequence word + iteration log of the resident structure-only solve
     int ps_host_entries = 0;
     DevBuf<double> ps_log;              // the same log on the device while the kernel runs
@@ -204,9 +231,10 @@ struct soslam_ba {
     ~soslam_ba()
     {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
-        if (host_raw) (void)hipHostFree(host_raw);
-        if (ps_host) (void)hipHostFree(ps_host);
-        for (unsigned char* u : up_host) if (u) (void)hipHostFree(u);
+        pinned_free(host_raw);
+        pinned_free(ps_host);
+        for (unsigned char* u : up_host) pinned_free(u);
+        if (pin_pool) (void)hipHostFree(pin_pool);
         if (stage) (void)hipHostFree(stage);
         rccl_comm_destroy(rccl);
         if (fstream) { (void)hipStreamSynchronize(fstream); (void)hipStreamDestroy(fstream); }
@@ -337,10 +365,10 @@ struct UploadBatch {
         }
         const size_t table_bytes = (segs.size() * sizeof(PackedSeg) + 15) & ~(size_t)15, need = table_bytes + total;
         if (need > h->up_host_bytes[region]) {
-            if (h->up_host[region]) (void)hipHostFree(h->up_host[region]);
+            h->pinned_free(h->up_host[region]);
             h->up_host[region] = nullptr; h->up_host_bytes[region] = 0;
-            const size_t cap = std::max<size_t>(need + need / 4, 1u << 16);
-            SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->up_host[region]), cap, hipHostMallocDefault));
+            const size_t cap = std::max<size_t>(need + need / 4, region == 1 ? (size_t)4096 : (size_t)(1u << 16));
+            SOSLAM_CHECK(h->pinned_alloc(reinterpret_cast<void**>(&h->up_host[region]), cap));
             h->up_host_bytes[region] = cap;
         }
         PackedSeg* table = reinterpret_cast<PackedSeg*>(h->up_host[region]);
@@ -1021,7 +1049,7 @@ int build_problem(soslam_ba* h, uint32_t n_cam, uint32_t n_pt, uint32_t n_obs, c
     SOSLAM_CHECK(zeros.flush(h, s, 1));
     h->reduce = h->reduce_own.p;
     if (!h->host_raw) {
-        SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->host_raw), sizeof(double) * (SC_COUNT + 4 + 1), hipHostMallocDefault));
+        SOSLAM_CHECK(h->pinned_alloc(reinterpret_cast<void**>(&h->host_raw), sizeof(double) * (SC_COUNT + 4 + 1)));
         h->host_scal = h->host_raw + 4;
         h->host_seq = reinterpret_cast<unsigned long long*>(h->host_raw + 4 + SC_COUNT);
         *h->host_seq = 0;
@@ -1739,11 +1767,10 @@ int run_points_resident(soslam_ba* h, int max_it, bool check, soslam_ba_summary*
     const int entries = max_it + 1;
     constexpr int kHead = PSV_COUNT + 1;   // record, sequence word
     if (entries > h->ps_host_entries) {
-        if (h->ps_host) (void)hipHostFree(h->ps_host);
+        h->pinned_free(h->ps_host);
         h->ps_host = nullptr; h->ps_host_entries = 0;
         const int cap = std::max(entries, 64);
-        SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->ps_host), sizeof(double) * ((size_t)kHead + (size_t)cap * kPointsLogDoubles),
-                                       hipHostMallocDefault));
+        SOSLAM_CHECK(h->pinned_alloc(reinterpret_cast<void**>(&h->ps_host), sizeof(double) * ((size_t)kHead + (size_t)cap * kPointsLogDoubles)));
         h->ps_host_entries = cap;
         *reinterpret_cast<unsigned long long*>(h->ps_host + PSV_COUNT) = 0;
     }
@@ -2001,10 +2028,10 @@ int state_staging(soslam_ba* h, size_t bytes, double** payload)
     static_assert(2 * sizeof(PackedSeg) <= kTable, "table room");
     const size_t need = kTable + bytes;
     if (need > h->up_host_bytes[2]) {
-        if (h->up_host[2]) (void)hipHostFree(h->up_host[2]);
+        h->pinned_free(h->up_host[2]);
         h->up_host[2] = nullptr; h->up_host_bytes[2] = 0;
         const size_t cap = std::max<size_t>(need + need / 4, 1u << 16);
-        SOSLAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->up_host[2]), cap, hipHostMallocDefault));
+        SOSLAM_CHECK(h->pinned_alloc(reinterpret_cast<void**>(&h->up_host[2]), cap));
         h->up_host_bytes[2] = cap;
     }
     *payload = reinterpret_cast<double*>(h->up_host[2] + kTable);
