@@ -210,6 +210,7 @@ struct soslam_ba {
     bool x_cost_known = false;          // x_cost is the cost at cams[cur], pts[cur] (accepted candidates: no sum over the tiles needed)
     bool campre_current = false;        // campre already holds the pose table of cams[cur] (set on acceptance, used once by linearize)
     bool points_only_ready = false;     // structure-only path: both pose tables / camera buffers hold the constant poses, dc_full is zero
+    bool points_resident_ready = false; // ... the resident solve's share of that: the pose table of the constant cameras
     int invalid_run = 0;
     std::vector<soslam_ba_iteration> log;
     std::vector<std::vector<uint32_t>> h_blk_contrib, h_cam_contrib;   // set-up scratch (build_problem), kept for its capacity
@@ -1775,12 +1776,11 @@ int run_points_resident(soslam_ba* h, int max_it, bool check, soslam_ba_summary*
         *reinterpret_cast<unsigned long long*>(h->ps_host + PSV_COUNT) = 0;
     }
     SOSLAM_CHECK(h->ps_log.alloc((size_t)h->ps_host_entries * kPointsLogDoubles));
-    if (!h->points_only_ready) {
+    // the kernel needs the constant cameras' pose table and nothing else (the candidate table, the second camera buffer and the zero
+    // camera step belong to the host-driven loop, which prepares them itself: points_only_ready)
+    if (!h->points_only_ready && !h->points_resident_ready) {
         launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre.p);
-        launch_pose_prepare(s, h->n_cam, h->cams[h->cur].p, h->campre_c.p);
-        SOSLAM_HIP_CHECK(hipMemcpyAsync(h->cams[h->cur ^ 1].p, h->cams[h->cur].p, sizeof(double) * 6 * h->n_cam, hipMemcpyDeviceToDevice, s));
-        SOSLAM_CHECK(h->dc_full.zero(s));
-        h->points_only_ready = true;
+        h->points_resident_ready = true;
     }
     PointsStepArgs a{};
     a.n_pt = h->n_pt; a.pt_start = h->pt_start.p; a.pt_obs = h->pt_obs.p; a.q_cam = h->q_cam.p; a.uv = h->uv.p;
@@ -2199,6 +2199,7 @@ int soslam_ba_set_state(soslam_ba* h, const double* poses, const double* points)
     h->linearized = false; h->x_cost_known = false;
     h->scale_init = false;
     h->points_only_ready = false;
+    h->points_resident_ready = false;
     h->campre_current = false;
     h->have_state = true;
     return SOSLAM_OK;
