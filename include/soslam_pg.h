@@ -29,11 +29,10 @@ extern "C" {
 enum { SOSLAM_PG_TERM_ITERATIONS = 0, SOSLAM_PG_TERM_TRIALS = 1, SOSLAM_PG_TERM_FAILURE = 2 };
 /* preconditioner of the PCG that stands in for g2o's LinearSolverEigen (a direct sparse Cholesky,
  * /root/reference/src/pose_graph_optimizer.cpp:14-18): block-Jacobi; block-Jacobi plus a coarse space of six rigid-body modes
- * per aggregate of neighbouring vertices (two-level); or - a chain of keyframes with a few loop closures, the reference's own
- * graphs - the exact factor of the band that holds the odometry chain (block cyclic reduction), the closure blocks staying in
- * the matrix-vector product only.  AUTO: the band factor when at least 99 % of the edges join vertices at most ten apart in the
- * order given and at most four do not (every closure costs that PCG about a dozen rounds), else two-level from 64 free vertices
- * on, else block-Jacobi */
+ * per aggregate of neighbouring vertices (two-level); or - a chain of keyframes with loop closures, the reference's own graphs -
+ * the exact factor of H as a band: numbered breadth-first such a graph has a half-bandwidth of a few vertices whatever the length
+ * of its loops (block cyclic reduction; edges the band of ten leaves out stay in the matrix-vector product).  AUTO: the band factor
+ * when at most four edges (and at most 1 %) lie outside the band, else two-level from 64 free vertices on, else block-Jacobi */
 enum { SOSLAM_PG_PRECOND_AUTO = 0, SOSLAM_PG_PRECOND_BLOCK_JACOBI = 1, SOSLAM_PG_PRECOND_TWO_LEVEL = 2, SOSLAM_PG_PRECOND_BAND_FACTOR = 3 };
 
 typedef struct soslam_pg_options {

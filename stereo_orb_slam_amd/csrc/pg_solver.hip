@@ -106,39 +106,72 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     // an aggregate is a contiguous range of block rows of H.
     constexpr uint32_t kAggMax = 42;   // block rows of one pcg2 workgroup
     const int pre = h->opt.preconditioner;
-    // a chain?  offsets of the edges' vertices in the order given (the reference numbers keyframes as they arrive)
+    // A chain with loop closures?  Ordered breadth-first (Cuthill-McKee: from the first free vertex, neighbours by ascending degree) a
+    // chain of keyframes with a handful of loop edges is a BAND whatever the length of the loops - a loop's two arms are numbered
+    // alternately, the closure edge joins neighbours - so H has an exact band factor and a solve is ONE round.  Edges the band of ten
+    // still leaves out (loops nested several deep) stay in the matrix-vector product, about a dozen PCG rounds apiece.
     h->band_mode = false; h->band_off = false; h->band_bw = 0;
     if (nf >= 32 && (pre == SOSLAM_PG_PRECOND_AUTO || pre == SOSLAM_PG_PRECOND_BAND_FACTOR) && std::getenv("SOSLAM_PG_NO_BAND") == nullptr) {
-        uint64_t within[kCrBandMax + 1] = {0}, pairs = 0;
-        for (uint32_t k = 0; k < n_edge; k++) {
-            const int32_t a = h->h_free[ef[k]], b = h->h_free[et[k]];
-            if (a < 0 || b < 0) continue;
-            pairs++;
-            const uint32_t d = (uint32_t)std::abs(a - b);
-            if (d <= (uint32_t)kCrBandMax) within[d]++;
+        std::vector<std::vector<uint32_t>> adj(n_vertex);
+        for (uint32_t k = 0; k < n_edge; k++)
+            if (h->h_free[ef[k]] >= 0 && h->h_free[et[k]] >= 0) { adj[ef[k]].push_back(et[k]); adj[et[k]].push_back(ef[k]); }
+        std::vector<int32_t> pos(n_vertex, -1);
+        {
+            std::vector<uint32_t> queue;
+            queue.reserve(nf);
+            for (uint32_t v0 = 0; v0 < n_vertex; v0++) {
+                if (h->h_free[v0] < 0 || pos[v0] >= 0) continue;
+                pos[v0] = (int32_t)queue.size();
+                queue.push_back(v0);
+                for (size_t qi = (size_t)pos[v0]; qi < queue.size(); qi++) {
+                    const uint32_t v = queue[qi];
+                    std::vector<uint32_t>& nb = adj[v];
+                    std::sort(nb.begin(), nb.end(), [&](uint32_t x, uint32_t y) { return adj[x].size() != adj[y].size() ? adj[x].size() < adj[y].size() : x < y; });
+                    for (uint32_t u : nb)
+                        if (pos[u] < 0) { pos[u] = (int32_t)queue.size(); queue.push_back(u); }
+                }
+            }
         }
-        uint64_t acc = 0;
-        int w = 0;
-        for (w = 1; w <= kCrBandMax; w++) {
-            acc += within[w];
-            if (acc * 100 >= pairs * 99) break;
-        }
-        if (pre == SOSLAM_PG_PRECOND_BAND_FACTOR && w > kCrBandMax) w = kCrBandMax;   // asked for: whatever lies outside stays in the matvec
-        if (pairs > 0 && w <= kCrBandMax) {
+        // the better of the two orders: breadth-first, or as given (the reference numbers keyframes as they arrive)
+        auto outside_of = [&](const std::vector<int32_t>& idx, uint64_t* pairs_out) {
+            uint64_t pairs = 0, in = 0;
+            for (uint32_t k = 0; k < n_edge; k++) {
+                const int32_t a_ = idx[ef[k]], b_ = idx[et[k]];
+                if (a_ < 0 || b_ < 0) continue;
+                pairs++;
+                if (std::abs(a_ - b_) <= kCrBandMax) in++;
+            }
+            *pairs_out = pairs;
+            return pairs - in;
+        };
+        uint64_t pairs = 0, pairs2 = 0;
+        const uint64_t out_bfs = outside_of(pos, &pairs), out_nat = outside_of(h->h_free, &pairs2);
+        const bool use_bfs = out_bfs < out_nat && std::getenv("SOSLAM_PG_NO_BFS") == nullptr;   // (the switch: tests of the off-band path)
+        const std::vector<int32_t>& idx = use_bfs ? pos : h->h_free;
+        const uint64_t outside = use_bfs ? out_bfs : out_nat;
+        // Every closure left to the matrix-vector product costs the PCG about a dozen rounds (it perturbs the preconditioned matrix by
+        // rank 12, and not by little), a round 95 us at 2 000 vertices against 18 us for an iteration of the two-level PCG, which needs
+        // ~270 of them on such a chain whatever the closures: measured in the order given (scripts/pg_chain_probe.py, ten iterations)
+        // 14 / 23 / 31 / 35 / 48 / 68 ms at 1 / 2 / 3 / 4 / 6 / 12 closures against 44-49 ms.  AUTO takes the band with up to four edges outside it
+        const bool fits = pairs > 0 && outside * 100 <= pairs && (pre == SOSLAM_PG_PRECOND_BAND_FACTOR || outside <= 4);
+        if (fits || (pre == SOSLAM_PG_PRECOND_BAND_FACTOR && pairs > 0)) {
             h->band_mode = true;
-            // super-blocks of nine vertices whatever the chain's own width (a tridiagonal chain factored in 6 x 6 nodes would be a
-            // tree of log2(n) levels of tiny inverses): ten only when the band needs it
-            h->band_bw = w <= 9 ? 9 : kCrBandMax;
-            uint64_t inside = 0;
-            for (int d = 1; d <= h->band_bw; d++) inside += within[d];
-            h->band_off = inside < pairs;
+            int wmax = 1;
+            for (uint32_t k = 0; k < n_edge; k++) {
+                const int32_t a_ = idx[ef[k]], b_ = idx[et[k]];
+                if (a_ >= 0 && b_ >= 0 && std::abs(a_ - b_) <= kCrBandMax) wmax = std::max(wmax, std::abs(a_ - b_));
+            }
+            // super-blocks of nine vertices whatever the band's own width (a tridiagonal chain factored in 6 x 6 nodes would be a tree
+            // of log2(n) levels of tiny inverses): ten only when the band needs it
+            h->band_bw = wmax <= 9 ? 9 : kCrBandMax;
+            uint64_t in = 0;
+            for (uint32_t k = 0; k < n_edge; k++) {
+                const int32_t a_ = idx[ef[k]], b_ = idx[et[k]];
+                if (a_ >= 0 && b_ >= 0 && std::abs(a_ - b_) <= h->band_bw) in++;
+            }
+            h->band_off = in < pairs;
             h->band_rounds = 2;
-            // Every closure left to the matrix-vector product costs the PCG about a dozen rounds (it perturbs the preconditioned
-            // matrix by rank 12, and not by little), a round 95 us at 2 000 vertices against 18 us for an iteration of the two-level
-            // PCG, which needs ~270 of them on such a chain whatever the closures: measured (scripts/pg_chain_probe.py, ten
-            // iterations) 14 / 23 / 31 / 35 / 48 / 68 ms at 1 / 2 / 3 / 4 / 6 / 12 closures against 44-49 ms.  AUTO takes the band up to
-            // four closures - the first loops of a run, which is when the reference calls this
-            if (pre == SOSLAM_PG_PRECOND_AUTO && pairs - inside > 4) h->band_mode = false;
+            if (use_bfs) h->h_free = pos;   // the free index IS the position in H
         }
     }
     h->two_level = !h->band_mode && nf > 0 && (pre == SOSLAM_PG_PRECOND_TWO_LEVEL || (pre == SOSLAM_PG_PRECOND_AUTO && nf >= 64)) && (nf + kAggMax - 1) / kAggMax * 6 <= 1200;
