@@ -1044,6 +1044,45 @@ def test_two_block_dense_solve_matches_the_blocked_cholesky(gpu):
             np.testing.assert_allclose(new["pts"], old["pts"], rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_small_problems_match_the_oracle(gpu, oracle_lib, seed):
+    """A sweep over the dispatch: 2 to 44 cameras (one-workgroup dense solves, the two-block elimination, the blocked Cholesky, the
+    block-Gauss-Jordan inverse, the band factor), tracks of 2 to 24 cameras (the 10-, 16-, 20- and 32-camera Schur windows), fixed
+    or geometric track lengths, one to all cameras constant (all: the resident structure-only solve), the reference's bounds or a
+    tight box, with and without Jacobi scaling.  Every case: AUTO solver, eight LM iterations against the oracle - acceptance
+    pattern, every iterate's cost, the final state."""
+    ba, synth, L = gpu
+    rng = np.random.default_rng(1000 + seed)
+    n_cam = int(rng.choice([2, 3, 5, 8, 11, 12, 19, 20, 21, 23, 24, 30, 36, 44]))
+    mode = int(rng.integers(0, 2))
+    track = int(min(n_cam, rng.choice([2, 3, 6, 10, 12, 17, 20, 24])))
+    if mode == 1:
+        track = max(track, 2)
+    p = synth.generate_ba(None, n_cam=n_cam, n_pt=int(rng.integers(20, 60)) * n_cam, track_mode=mode, track_len=track, spacing=float(rng.choice([0.2, 0.5, 0.9])))
+    fixed = np.zeros(n_cam, np.uint8)
+    fixed[0] = 1
+    kind = int(rng.integers(0, 4))
+    if kind == 1 and n_cam > 3:
+        fixed[rng.choice(np.arange(1, n_cam), size=max(1, n_cam // 4), replace=False)] = 1
+    elif kind == 2:
+        fixed[:] = 1
+    bound = float(rng.choice([1e4, 1e4, 60.0]))
+    q = synth.BaProblem(p.poses_wc, np.clip(p.points, -bound, bound), p.obs_cam, p.obs_pt, p.obs_uv, p.proj_l, p.proj_r, cam_fixed=fixed)
+    kw = dict(max_iterations=8, check_termination=0, lower_bound=-bound, upper_bound=bound, jacobi_scaling=int(rng.integers(0, 2)))
+    ocams, opts_, osum, olog = _oracle_solve(oracle_lib, q, **kw)
+    with ba.BundleAdjustment(ba.default_options(**kw)) as h:
+        h.load(q)
+        summ = h.solve()
+        cams, pts = h.get_state()
+        log = h.iteration_log()
+    tag = f"seed {seed}: {n_cam} cameras ({int(fixed.sum())} constant), tracks {'fixed' if mode == 0 else 'geometric'} {track}, bound {bound}, solver {summ.linear_solver}"
+    assert [e.accepted for e in log] == [e.accepted for e in olog] and [e.valid for e in log] == [e.valid for e in olog], tag
+    np.testing.assert_allclose([e.cost for e in log], [e.cost for e in olog], rtol=1e-6, err_msg=tag)
+    assert summ.line_search_steps == osum.line_search_steps, tag
+    np.testing.assert_array_equal(cams[fixed == 1], q.poses_cw()[fixed == 1])
+    _compare_solutions(summ, cams, pts, osum, ocams, opts_)
+
+
 def test_fused_launches_of_small_problems_match_the_separate_ones(gpu):
     """At most 32 cameras on one rank: candidate cameras, back-substitution, candidate cost and the step sums are one launch
     (ba_apply_small; its last workgroup sums and publishes).  The separate launches it replaces (SOSLAM_NO_APPLY_FUSE) and the
