@@ -209,6 +209,43 @@ def test_chain_with_loop_closures_takes_the_band_factor(gpu, oracle_lib):
     assert res[0] == res[2] and res[0] > 100, res
 
 
+@pytest.mark.parametrize("case", ["fixed_in_the_middle", "two_components", "shuffled_ids", "several_fixed"])
+def test_band_factor_on_awkward_chains(gpu, oracle_lib, case):
+    """Shapes the breadth-first numbering of the band path must cope with: the constant vertex in the middle of the chain (two free
+    arms), two chains that are not connected (the second without a constant vertex: only the Levenberg shift makes its block
+    definite), vertex ids that do not follow the chain (the caller's order is arbitrary), several constant vertices.  Each against the
+    oracle's ten iterations."""
+    pg, synth, L = gpu
+    c = synth.generate_pg(5, n_node=400, row_len=400, n_loop_max=3, min_gap=50, radius=80.0)
+    est, ef, et, meas, fixed = c.est.copy(), c.e_from.copy(), c.e_to.copy(), c.meas.copy(), c.fixed.copy()
+    if case == "fixed_in_the_middle":
+        fixed[:] = 0
+        fixed[200] = 1
+    elif case == "two_components":
+        keep = ~(((ef < 250) & (et >= 250)) | ((et < 250) & (ef >= 250)))     # cut every edge across vertex 250
+        ef, et, meas = ef[keep], et[keep], meas[keep]
+    elif case == "shuffled_ids":
+        perm = np.random.default_rng(3).permutation(len(est))
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(len(perm))
+        est, fixed = est[perm], fixed[perm]                                   # new id k holds old vertex perm[k]
+        ef, et = inv[ef].astype(np.uint32), inv[et].astype(np.uint32)
+    else:
+        fixed[[0, 133, 399]] = 1
+    g = synth.PgProblem(est, ef, et, meas, fixed, c.info)
+    oest, osum, olog = _oracle_solve(oracle_lib, g, iters=10)
+    with pg.PoseGraph(pg.default_options(max_iterations=10)) as h:
+        h.load(g)
+        s = h.optimize()
+        out, log = h.estimates(), h.iteration_log()
+    assert s.iterations == osum.iterations
+    for a, b in zip(log, olog):
+        assert a.chi2 == pytest.approx(b.chi2, rel=1e-5, abs=1e-12) and a.trials == b.trials
+    np.testing.assert_allclose(out[:, :3], oest[:, :3], atol=1e-4)
+    _same_rotation(out[:, 3:], oest[:, 3:], 1e-4)
+    assert max(it.linear_iterations / max(1, it.trials) for it in log) <= 2, [(it.linear_iterations, it.trials) for it in log]
+
+
 def test_linearisation_is_bitwise_reproducible(gpu):
     """H and b are summed from per-edge records through fixed-order lists (pg_gather), not by floating-point atomics: two
     linearisations of the same estimates agree bit for bit, and so do two whole solves."""
