@@ -174,9 +174,11 @@ __device__ __forceinline__ void coop_sum3(const double* __restrict__ a, const do
 }
 
 // q_row of (A p) with p = z + beta p_old formed on the fly (FIRST: p is p_old itself, the init kernel's z)
+// (sub, lanes): this lane's share of the row - entries sub, sub + lanes, ... - for callers that put several lanes on a row and add
+// their sums (pcg2_matvec on small aggregates)
 template <bool FIRST>
 __device__ __forceinline__ double bsr_row_dot_dir(const BsrView& A, uint32_t row, const double* __restrict__ z,
-                                                  const double* __restrict__ p_old, double beta)
+                                                  const double* __restrict__ p_old, double beta, const uint32_t sub = 0, const uint32_t lanes = 1)
 {
     const uint32_t f = row / 6, a = row % 6;
     double s = 0.0;
@@ -185,13 +187,13 @@ __device__ __forceinline__ double bsr_row_dot_dir(const BsrView& A, uint32_t row
     // dependent gathers, 10.5 us per launch at configs[4]).  The products are added in the row's order: the bits do not change.
     constexpr int kRowUnroll = 8;
     const uint32_t e_end = A.row_ptr[f + 1];
-    for (uint32_t e0 = A.row_ptr[f]; e0 < e_end; e0 += kRowUnroll) {
+    for (uint32_t e0 = A.row_ptr[f] + sub; e0 < e_end; e0 += kRowUnroll * lanes) {
         uint32_t blk[kRowUnroll], col[kRowUnroll];
         bool tr[kRowUnroll], on[kRowUnroll];
 #pragma unroll
         for (int u = 0; u < kRowUnroll; u++) {
-            on[u] = e0 + u < e_end;
-            const uint32_t e = on[u] ? e0 + u : e0;
+            on[u] = e0 + u * lanes < e_end;
+            const uint32_t e = on[u] ? e0 + u * lanes : e0;
             blk[u] = A.ent_blk[e]; col[u] = A.ent_col[e]; tr[u] = A.ent_trans[e] != 0;
         }
         double bv[kRowUnroll][6], xv[kRowUnroll][6];
@@ -418,13 +420,25 @@ __global__ __launch_bounds__(kThreads) void pcg2_matvec_kernel(const BsrView A, 
     __shared__ double qloc[kRowsPerWg * 6], yl[kRowsPerWg * 6];
     double pq = 0.0;
     const bool act = t < (int)(nr * 6);
-    if (act) {
-        const double pi = FIRST ? p_old[i] : w.z[i] + beta * p_old[i];
-        if (!FIRST) w.p[parity][i] = pi;
-        const double qi = bsr_row_dot_dir<FIRST>(A, i, w.z, p_old, beta) + shift * pi;
-        w.q[i] = qi;
-        qloc[t] = qi;
-        pq = pi * qi;
+    // A small aggregate (the BA path's six cameras: 36 rows of ~39 blocks each) leaves most of the workgroup idle with a lane per row:
+    // four (or two) lanes share a row's blocks and add their sums by DPP
+    const uint32_t rows = nr * 6;
+    const uint32_t L = rows * 4 <= (uint32_t)kThreads ? 4u : (rows * 2 <= (uint32_t)kThreads ? 2u : 1u);   // uniform in the workgroup
+    {
+        const uint32_t row_l = (uint32_t)t / L, sub = (uint32_t)t % L;
+        const bool on = row_l < rows;
+        const uint32_t ir = r0 * 6 + (on ? row_l : 0u);
+        double part = on ? bsr_row_dot_dir<FIRST>(A, ir, w.z, p_old, beta, sub, L) : 0.0;
+        if (L == 4) part = quad_sum(part);
+        else if (L == 2) part += mov_dpp_f64<kDppXor1>(part);
+        if (on && sub == 0) {
+            const double pi = FIRST ? p_old[ir] : w.z[ir] + beta * p_old[ir];
+            if (!FIRST) w.p[parity][ir] = pi;
+            const double qi = part + shift * pi;
+            w.q[ir] = qi;
+            qloc[row_l] = qi;
+            pq = pi * qi;
+        }
     }
     pq = block_sum256(pq, red);   // (its barriers: qloc is complete behind it)
     if (t == 0) w.part_pq[blockIdx.x] = pq;
