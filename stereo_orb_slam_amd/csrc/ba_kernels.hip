@@ -2264,7 +2264,12 @@ __global__ __launch_bounds__(kPointBlock) void ba_apply_small_kernel(
     step_sums_body<kPointBlock, true>(sums, red, fin);
 }
 
-bool apply_small_fits(uint32_t n_cam, uint32_t n_pt) { return n_cam >= 1 && n_cam <= (uint32_t)kApplySmallCams && n_pt >= 1; }
+// (every workgroup forms all candidate cameras for itself, and every workgroup adds to ONE arrival counter: a shape for small
+// problems - up to 64 k points, 1 024 workgroups)
+bool apply_small_fits(uint32_t n_cam, uint32_t n_pt)
+{
+    return n_cam >= 1 && n_cam <= (uint32_t)kApplySmallCams && n_pt >= 1 && backsub_blocks(n_pt) <= 1024u;
+}
 
 void launch_apply_small(hipStream_t s, uint32_t n_cam, const int32_t* cam_free, const double* cams, const double* dc_free, const double* lc,
                         const double* gc_red, const double* lin_resid, double* cams_out, double* dc_full, double* dcw, double* cam_part,
