@@ -111,7 +111,8 @@ int build_graph(soslam_pg* h, uint32_t n_vertex, const double* est, const uint8_
     // alternately, the closure edge joins neighbours - so H has an exact band factor and a solve is ONE round.  Edges the band of ten
     // still leaves out (loops nested several deep) stay in the matrix-vector product, about a dozen PCG rounds apiece.
     h->band_mode = false; h->band_off = false; h->band_bw = 0;
-    if (nf >= 32 && (pre == SOSLAM_PG_PRECOND_AUTO || pre == SOSLAM_PG_PRECOND_BAND_FACTOR) && std::getenv("SOSLAM_PG_NO_BAND") == nullptr) {
+    // (the factor's workspace is 187 KB per nine vertices: 4 GB at 200 000 vertices, where this path ends)
+    if (nf >= 32 && nf <= 200000 && (pre == SOSLAM_PG_PRECOND_AUTO || pre == SOSLAM_PG_PRECOND_BAND_FACTOR) && std::getenv("SOSLAM_PG_NO_BAND") == nullptr) {
         std::vector<std::vector<uint32_t>> adj(n_vertex);
         for (uint32_t k = 0; k < n_edge; k++)
             if (h->h_free[ef[k]] >= 0 && h->h_free[et[k]] >= 0) { adj[ef[k]].push_back(et[k]); adj[et[k]].push_back(ef[k]); }
